@@ -1,0 +1,133 @@
+"""CPU tests pinning the oracle (oracle/radix_sort_cpu.hpp).
+
+Pins, in order of authority:
+ 1. tests/golden/oracle_golden.json — produced by the reference's own headers
+    (oracle/make_golden.py via oracle/_ref); checked everywhere, including the GPU box.
+ 2. oracle/_ref itself, when present: restatement == reference byte-for-byte on a
+    matrix of inputs and on fuzzed inputs.
+ 3. Sample values the survey recorded from the reference headers.
+"""
+import numpy as np
+import pytest
+
+DT = ["uint32", "int32", "uint64", "int64"]
+KINDS = ["Zeros", "Range", "InvertedRange", "Random"]
+
+
+def test_golden_dataset_and_sort_digests(oracle, golden):
+    for row in golden["datasets"]:
+        src = oracle.dataset(row["kind"], row["dtype"], row["n"])
+        assert oracle.digest(src) == row["input_digest"], row
+        srt = oracle.radix_sort(src)
+        assert oracle.digest(srt) == row["sorted_digest"], row
+        assert (int(srt[0]), int(srt[row["n"] // 2]), int(srt[-1])) == (row["first"], row["mid"], row["last"])
+
+
+def test_golden_known_answers_incl_reference_defects(oracle, golden):
+    # Includes inputs on which the reference's round count is short (exact powers of
+    # the base, max == 1, signed data with small raw max): the restatement must
+    # reproduce those wrong-but-faithful outputs too.
+    for row in golden["known_answers"]:
+        src = np.array(row["input"], dtype=row["dtype"])
+        got = oracle.radix_sort(src)
+        assert [int(v) for v in got] == row["output"], row
+
+
+def test_golden_small_vectors(oracle, golden):
+    for row in golden["small_vectors"]:
+        src = oracle.dataset(row["kind"], row["dtype"], row["n"])
+        assert [int(v) for v in src] == row["input"]
+        assert [int(v) for v in oracle.radix_sort(src)] == row["sorted"]
+
+
+def test_survey_recorded_samples(oracle, golden):
+    # first 8 Random values and first/mid/last of the sorted 2^16 arrays.
+    first8 = [2421477274, 811668573, 145020712, 106868501, 1537199182, 2398500640, 300868536, 942266821]
+    assert [int(v) for v in oracle.dataset("Random", "uint32", 8)] == first8
+    assert [int(v) for v in oracle.dataset("Random", "uint64", 8)] == first8       # zero-extended 32-bit draws
+    assert golden["random_first8"]["uint32"] == first8
+    s = oracle.radix_sort(oracle.dataset("Random", "uint32", 65536))
+    assert (int(s[0]), int(s[32768]), int(s[-1])) == (4912, 2139437887, 4294934524)
+    s = oracle.radix_sort(oracle.dataset("Random", "int32", 65536))
+    assert (int(s[0]), int(s[-1])) == (-2147378835, 2147323870)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_restatement_equals_reference_matrix(oracle, ref_oracle, dt):
+    for kind in KINDS:
+        for n in (1, 2, 7, 1000, 1024, 4096, 65536):
+            a = oracle.dataset(kind, dt, n)
+            b = ref_oracle.dataset(kind, dt, n)
+            assert np.array_equal(a, b), (kind, n)
+            if np.dtype(dt).kind == "i" and int(a.max()) == np.iinfo(dt).min:
+                # Raw maximum == numeric_limits::min(): the reference negates it in the
+                # signed type (for int32 through C's abs(int), which wins overload
+                # resolution over CRadixSortCPU.h:20-25) — undefined behaviour that
+                # ends in a division by zero here.  Outside the oracle's domain.
+                continue
+            assert np.array_equal(oracle.radix_sort(a), ref_oracle.radix_sort(b)), (kind, n)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_restatement_equals_reference_fuzz(oracle, ref_oracle, dt):
+    rng = np.random.default_rng(1234)
+    info = np.iinfo(dt)
+    for trial in range(60):
+        n = int(rng.integers(1, 3000))
+        # mix of magnitudes so short round counts (the reference's defect) are hit too
+        hi = [7, 8, 63, 64, 511, 4096, 2**20, int(info.max)][trial % 8]
+        lo = 0 if info.min == 0 or trial % 3 else max(int(info.min), -hi)
+        x = rng.integers(lo, hi, size=n, dtype=dt, endpoint=True)
+        assert np.array_equal(oracle.radix_sort(x), ref_oracle.radix_sort(x)), (trial, n, lo, hi)
+        assert oracle.round_count(x) >= 0
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_oracle_correct_domain_matches_std_sort(oracle, dt):
+    # On every BASELINE input family the oracle equals std::sort.
+    for kind in KINDS + ["SeededUniform"]:
+        x = oracle.dataset(kind, dt, 20000)
+        assert np.array_equal(oracle.radix_sort(x), oracle.std_sort(x)), kind
+        assert np.array_equal(oracle.std_sort(x), np.sort(x))
+
+
+def test_seeded_uniform_shape(oracle):
+    for dt in DT:
+        x = oracle.dataset("SeededUniform", dt, 4096)
+        info = np.iinfo(dt)
+        assert x[0] == info.max and x[-1] == info.min          # Dataset.h:105-106
+        assert np.array_equal(x, oracle.dataset("SeededUniform", dt, 4096))   # reproducible
+        assert not np.array_equal(x, oracle.dataset("SeededUniform", dt, 4096, seed=99))
+    x64 = oracle.dataset("SeededUniform", "uint64", 4096)
+    assert (x64[1:-1] >> np.uint64(32)).any()                     # real 64-bit entropy
+
+
+def test_payload_extension_is_stable_argsort(oracle):
+    rng = np.random.default_rng(7)
+    for dt in DT:
+        info = np.iinfo(dt)
+        x = rng.integers(0, 50, size=5000, dtype=dt)          # many ties
+        x[::17] = info.max                                      # keep the round count full
+        p = np.arange(x.size, dtype=np.uint32)
+        ks, ps = oracle.radix_sort(x, p)
+        assert np.array_equal(ks, np.sort(x, kind="stable"))
+        assert np.array_equal(ps, np.argsort(x, kind="stable").astype(np.uint32))
+        assert np.array_equal(ps, oracle.stable_argsort(x, p))
+
+
+def test_reference_gpu_structure_emulation(oracle):
+    # The host emulation of the reference's 1024-virtual-processor pass structure
+    # sorts correctly and its last-pass table is a global exclusive prefix.
+    for dt in ("uint32", "int64"):
+        x = oracle.dataset("Random", dt, 8192)
+        s, table, globsum = oracle.emulate_reference_gpu(x)
+        assert np.array_equal(s, np.sort(x))
+        assert table[0] == 0 and np.all(np.diff(table.astype(np.int64)) >= 0)
+        assert globsum[0] == 0 and np.all(np.diff(globsum.astype(np.int64)) >= 0)
+        assert int(table[-1]) <= x.size
+
+
+def test_empty_and_single(oracle):
+    for dt in DT:
+        assert oracle.radix_sort(np.array([], dtype=dt)).size == 0
+        assert [int(v) for v in oracle.radix_sort(np.array([5], dtype=dt))] == [5]
