@@ -1,0 +1,169 @@
+/* radixsort_hip.h — C ABI of the MI355X (gfx950) LSD radix-sort engine.
+ *
+ * This is the drop-in boundary for the reference's GPU hot path: the private
+ * steps of RadixSortGPU<T> (/root/reference/src/RadixSortGPU.h:95-109) and the
+ * device-buffer set of ComputeDeviceData<T> (src/ComputeDeviceData.cpp:42-77),
+ * re-expressed as plain C so that C++ (radix-sort_amd/host), ctypes, cgo or JNI
+ * hosts bind the same symbols.  No C++ types, no exceptions and no ownership
+ * transfer cross this boundary.  Every function returns an rsx_status whose
+ * values map 1:1 onto the reference's `enum class OperationStatus`
+ * (src/OperationStatus.h:4-17).
+ *
+ * One engine = one device + one HIP stream + one set of device buffers
+ * (inputKeys/outputKeys ping-pong, optional uint32 payload ping-pong, digit
+ * table, block sums).  Engines share nothing; an engine is not thread-safe
+ * (same as the reference, which swaps buffer names in place,
+ * src/RadixSortGPU.cpp:263-266).
+ *
+ * There is no CPU fallback behind these symbols: without a HIP device every
+ * entry point that needs one fails with RSX_INITIALIZATION_FAILED.
+ */
+#ifndef RADIXSORT_HIP_H
+#define RADIXSORT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* == OperationStatus (src/OperationStatus.h:4-17), same order, same values == */
+typedef enum rsx_status {
+    RSX_OK = 0,
+    RSX_HOST_BUFFERS_FAILED = 1,
+    RSX_INITIALIZATION_FAILED = 2,
+    RSX_DATA_UPLOAD_FAILED = 3,
+    RSX_CALCULATION_FAILED = 4,
+    RSX_DATA_DOWNLOAD_FAILED = 5,
+    RSX_CLEANUP_FAILED = 6,
+    RSX_RESIZE_FAILED = 7,
+    RSX_KERNEL_CREATION_FAILED = 8,   /* unreachable: kernels are AOT-compiled for gfx950 */
+    RSX_PROGRAM_CREATION_FAILED = 9,  /* unreachable, kept for value parity */
+    RSX_NO_SOURCE_FOUND = 10,         /* unreachable, kept for value parity */
+    RSX_LOADING_SOURCE_FAILED = 11    /* unreachable, kept for value parity */
+} rsx_status;
+
+typedef struct rsx_engine rsx_engine;   /* opaque */
+
+/* Digit geometry of the sort: 4-bit digits, 16 buckets, bits/4 passes
+ * (src/Parameters.h:25,45,47). */
+#define RSX_RADIX_BITS 4
+#define RSX_RADIX 16
+
+/* Options for rsx_set_option. */
+typedef enum rsx_option {
+    RSX_OPT_PROFILE = 0,      /* 1: bracket every kernel launch with HIP events (RuntimesGPU) */
+    RSX_OPT_XCD_REMAP = 1,    /* 1 (default): consecutive tiles run on one XCD (L2 merges run seams) */
+    RSX_OPT_FIRST_PASS = 2,   /* first pass of rsx_sort (default 0) */
+    RSX_OPT_LAST_PASS = 3     /* one past the last pass of rsx_sort (default bits/4) */
+} rsx_option;
+
+/* Per-phase launch timings in milliseconds, the RuntimesGPU fields
+ * (src/RadixSortGPU.h:18-24) with Statistics semantics (src/Statistics.h). */
+typedef struct rsx_phase_stat {
+    double min_ms, max_ms, avg_ms, sum_ms;
+    uint64_t n;
+} rsx_phase_stat;
+
+typedef struct rsx_runtimes {
+    rsx_phase_stat histogram;  /* timeHisto   */
+    rsx_phase_stat scan;       /* timeScan    (two launches per pass, as in the reference) */
+    rsx_phase_stat paste;      /* timePaste   */
+    rsx_phase_stat reorder;    /* timeReorder */
+    rsx_phase_stat total;      /* whole rsx_sort calls (first launch -> last launch done) */
+} rsx_runtimes;
+
+typedef struct rsx_geometry {
+    uint32_t tile_threads;     /* workgroup size of histogram/reorder */
+    uint32_t keys_per_thread;
+    uint32_t tile_keys;        /* keys per tile = table column */
+    uint32_t scan_block;       /* table entries per scan workgroup */
+    uint64_t num_keys;         /* active length (rsx_resize / rsx_upload) */
+    uint64_t capacity;
+    uint64_t num_tiles;        /* ceil(num_keys / tile_keys) */
+    uint64_t table_len;        /* RSX_RADIX * num_tiles, layout [digit][tile] */
+    uint64_t num_scan_blocks;  /* ceil(table_len / scan_block) = live entries of globsum */
+    uint32_t num_passes;       /* key bits / 4 */
+    uint32_t key_bytes;
+} rsx_geometry;
+
+/* ---- device --------------------------------------------------------------- */
+/* Replaces ComputeState::init's device discovery (Common/ComputeState.cpp:14-104). */
+int rsx_device_count(int* count);
+int rsx_device_name(int device, char* buf, size_t buflen);
+const char* rsx_last_error(void);   /* thread-local text of the last failure */
+const char* rsx_version(void);
+
+/* ---- lifetime ---------------------------------------------------------------
+ * rsx_create replaces RadixSortGPU<T>::initialize (src/RadixSortGPU.cpp:452-543)
+ * + ComputeDeviceData's constructor: allocates inputKeys/outputKeys
+ * (capacity*key_bytes each), inputPermutations/outputPermutations
+ * (capacity*4 each, only with has_payload), the digit table and block sums.
+ * key_bytes is 4 or 8; is_signed selects the OFFSET treatment of signed keys
+ * (src/RadixSortGPU.cpp:436-440, RadixSort.cl:51,114).  The engine creates its
+ * own stream; rsx_set_stream substitutes a caller-owned hipStream_t.
+ * rsx_destroy replaces release() (src/RadixSortGPU.cpp:445-449). */
+int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int has_payload, uint64_t capacity);
+int rsx_destroy(rsx_engine* e);
+int rsx_set_stream(rsx_engine* e, void* hip_stream);
+int rsx_set_option(rsx_engine* e, int option, int64_t value);
+int rsx_get_geometry(const rsx_engine* e, rsx_geometry* out);
+
+/* Sets the active number of keys (any value <= capacity; the reference's
+ * 1024-rounding lives in the host class, RadixSortGPU::Resize,
+ * src/RadixSortGPU.cpp:288-297). */
+int rsx_resize(rsx_engine* e, uint64_t num_keys);
+
+/* ---- transfers ------------------------------------------------------------
+ * rsx_upload   = CopyDataToDevice + finish (src/RadixSortGPU.cpp:300-308,366-387):
+ *                host keys -> inputKeys, host perm -> inputPermutations (payload
+ *                engines only; perm may be NULL otherwise).  Sets num_keys = n.
+ * rsx_fill_pad = padGPUData (:270-285): fills inputKeys from byte_offset to the
+ *                end of the active length with numeric_limits<T>::max()-1.
+ * rsx_download = CopyDataFromDevice + finish (:349-357,390-429): sorted keys,
+ *                payload (NULL to skip), the first hist_cap entries of the digit
+ *                table and the first globsum_cap block sums of the last pass. */
+int rsx_upload(rsx_engine* e, const void* host_keys, const uint32_t* host_perm, uint64_t n);
+int rsx_fill_pad(rsx_engine* e, uint64_t byte_offset);
+int rsx_download(rsx_engine* e, void* host_keys_out, uint32_t* host_perm_out,
+                 uint32_t* hist_out, uint64_t hist_cap, uint32_t* globsum_out, uint64_t globsum_cap);
+
+/* ---- the hot path, step by step ---------------------------------------------
+ * Asynchronous on the engine's stream; no host synchronisation inside.
+ * rsx_histogram = RadixSortGPU::Histogram        (src/RadixSortGPU.cpp:16-61)
+ * rsx_scan      = ScanHistogram, scans #1 and #2 (:64-152)
+ * rsx_paste     = ScanHistogram, paste part      (:155-195)
+ * rsx_reorder   = Reorder incl. the buffer swap  (:199-267)
+ * rsx_sort      = calculate's pass loop          (:311-346) */
+int rsx_histogram(rsx_engine* e, int pass);
+int rsx_scan(rsx_engine* e);
+int rsx_paste(rsx_engine* e);
+int rsx_reorder(rsx_engine* e, int pass);
+int rsx_sort(rsx_engine* e);
+int rsx_sync(rsx_engine* e);   /* CommandQueue.finish() */
+
+/* ---- device-resident callers (PyTorch / RCCL plumbing) ----------------------
+ * rsx_sort_from: sorts n keys that already live in HBM at d_keys (16-byte
+ *   aligned, not modified) with optional payload d_payload; the result stays in
+ *   the engine (rsx_result_device / rsx_copy_result / rsx_download).
+ * rsx_partition: ONE stable radix pass on the bit field [shift, shift+bits) of
+ *   external keys into caller-provided output buffers; bucket_offsets receives
+ *   (1<<bits)+1 exclusive offsets.  This is the bucket-grouping step of the
+ *   multi-GPU exchange.  Synchronises the stream before returning. */
+int rsx_sort_from(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n);
+int rsx_partition(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n,
+                  int shift, int bits, void* d_keys_out, uint32_t* d_payload_out, uint64_t* bucket_offsets);
+int rsx_result_device(rsx_engine* e, void** d_keys, uint32_t** d_payload);
+int rsx_copy_result(rsx_engine* e, void* d_keys_out, uint32_t* d_payload_out);
+
+/* ---- measurements ------------------------------------------------------------
+ * rsx_timings synchronises, folds pending HIP-event pairs into the statistics and
+ * copies them out (getRuntimes, src/RadixSortGPU.cpp:591-595); reset != 0 clears
+ * them afterwards. */
+int rsx_timings(rsx_engine* e, rsx_runtimes* out, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RADIXSORT_HIP_H */

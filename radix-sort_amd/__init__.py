@@ -1,0 +1,293 @@
+"""radix-sort_amd — MI355X-native LSD radix sort behind the reference's RadixSortGPU API.
+
+This module is the Python-side binding of the C ABI in include/radixsort_hip.h
+(ctypes over radix-sort_amd/libradixsort_hip.so).  It carries no sort logic: every
+method is one C-ABI call.  The C++20 host mirror of the reference interface
+(RadixSortGPU<T>, CRadixSortTask<T>, Dataset<T>, ...) lives in radix-sort_amd/host/.
+
+There is no CPU fallback: if the HIP library is missing, or no GPU is present when an
+engine is created, this raises.
+
+The directory name contains a hyphen, so load it with `importlib` (see
+__graft_entry__.load_package()) under the module name `radix_sort_amd`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import importlib.util
+import os
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libradixsort_hip.so")
+
+# OperationStatus (reference src/OperationStatus.h:4-17)
+STATUS_NAMES = [
+    "OK", "HOST_BUFFERS_FAILED", "INITIALIZATION_FAILED", "DATA_UPLOAD_FAILED", "CALCULATION_FAILED",
+    "DATA_DOWNLOAD_FAILED", "CLEANUP_FAILED", "RESIZE_FAILED", "KERNEL_CREATION_FAILED",
+    "PROGRAM_CREATION_FAILED", "NO_SOURCE_FOUND", "LOADING_SOURCE_FAILED",
+]
+
+OPT_PROFILE, OPT_XCD_REMAP, OPT_FIRST_PASS, OPT_LAST_PASS = 0, 1, 2, 3
+
+# every symbol include/radixsort_hip.h declares (tests/test_capi_symbols.py checks the header against this)
+SYMBOLS = [
+    "rsx_device_count", "rsx_device_name", "rsx_last_error", "rsx_version",
+    "rsx_create", "rsx_destroy", "rsx_set_stream", "rsx_set_option", "rsx_get_geometry", "rsx_resize",
+    "rsx_upload", "rsx_fill_pad", "rsx_download",
+    "rsx_histogram", "rsx_scan", "rsx_paste", "rsx_reorder", "rsx_sort", "rsx_sync",
+    "rsx_sort_from", "rsx_partition", "rsx_result_device", "rsx_copy_result", "rsx_timings",
+]
+
+
+class PhaseStat(C.Structure):
+    _fields_ = [("min_ms", C.c_double), ("max_ms", C.c_double), ("avg_ms", C.c_double), ("sum_ms", C.c_double), ("n", C.c_uint64)]
+
+
+class Runtimes(C.Structure):   # RuntimesGPU (reference src/RadixSortGPU.h:18-24)
+    _fields_ = [("histogram", PhaseStat), ("scan", PhaseStat), ("paste", PhaseStat), ("reorder", PhaseStat), ("total", PhaseStat)]
+
+
+class Geometry(C.Structure):
+    _fields_ = [
+        ("tile_threads", C.c_uint32), ("keys_per_thread", C.c_uint32), ("tile_keys", C.c_uint32), ("scan_block", C.c_uint32),
+        ("num_keys", C.c_uint64), ("capacity", C.c_uint64), ("num_tiles", C.c_uint64), ("table_len", C.c_uint64),
+        ("num_scan_blocks", C.c_uint64), ("num_passes", C.c_uint32), ("key_bytes", C.c_uint32),
+    ]
+
+
+class RadixSortError(RuntimeError):
+    def __init__(self, status: int, where: str, detail: str = ""):
+        self.status = status
+        name = STATUS_NAMES[status] if 0 <= status < len(STATUS_NAMES) else str(status)
+        super().__init__(f"{where}: OperationStatus::{name}" + (f" ({detail})" if detail else ""))
+
+
+_lib = None
+
+
+def _share_hip_runtime_with_torch() -> None:
+    """One HIP runtime per process.  The PyTorch wheel bundles its own libamdhip64.so
+    (soname libamdhip64.so.7, but its users ask for it as `libamdhip64.so`); if this
+    library pulled in /opt/rocm's copy first, a later `import torch` would map a second
+    runtime and find no GPU.  When PyTorch is installed, map its copy first so both sides
+    bind the same one.  RSX_NO_TORCH_RUNTIME=1 opts out (pure C/C++ hosts never get here)."""
+    if os.environ.get("RSX_NO_TORCH_RUNTIME") or "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
+def load_library() -> C.CDLL:
+    """dlopen the HIP library; fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    _share_hip_runtime_with_torch()
+    lib = C.CDLL(LIB_PATH)
+    P, U64, I = C.c_void_p, C.c_uint64, C.c_int
+    sig = {
+        "rsx_device_count": ([C.POINTER(I)], I),
+        "rsx_device_name": ([I, C.c_char_p, C.c_size_t], I),
+        "rsx_last_error": ([], C.c_char_p),
+        "rsx_version": ([], C.c_char_p),
+        "rsx_create": ([C.POINTER(P), I, I, I, I, U64], I),
+        "rsx_destroy": ([P], I),
+        "rsx_set_stream": ([P, P], I),
+        "rsx_set_option": ([P, I, C.c_int64], I),
+        "rsx_get_geometry": ([P, C.POINTER(Geometry)], I),
+        "rsx_resize": ([P, U64], I),
+        "rsx_upload": ([P, P, P, U64], I),
+        "rsx_fill_pad": ([P, U64], I),
+        "rsx_download": ([P, P, P, P, U64, P, U64], I),
+        "rsx_histogram": ([P, I], I),
+        "rsx_scan": ([P], I),
+        "rsx_paste": ([P], I),
+        "rsx_reorder": ([P, I], I),
+        "rsx_sort": ([P], I),
+        "rsx_sync": ([P], I),
+        "rsx_sort_from": ([P, P, P, U64], I),
+        "rsx_partition": ([P, P, P, U64, I, I, P, P, C.POINTER(U64)], I),
+        "rsx_result_device": ([P, C.POINTER(P), C.POINTER(P)], I),
+        "rsx_copy_result": ([P, P, P], I),
+        "rsx_timings": ([P, C.POINTER(Runtimes), I], I),
+    }
+    for name, (args, res) in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = res
+    _lib = lib
+    return lib
+
+
+def device_count() -> int:
+    lib = load_library()
+    n = C.c_int(0)
+    rc = lib.rsx_device_count(C.byref(n))
+    if rc != 0:
+        raise RadixSortError(rc, "rsx_device_count", lib.rsx_last_error().decode())
+    return n.value
+
+
+def device_name(device: int = 0) -> str:
+    lib = load_library()
+    buf = C.create_string_buffer(256)
+    rc = lib.rsx_device_name(device, buf, 256)
+    if rc != 0:
+        raise RadixSortError(rc, "rsx_device_name", lib.rsx_last_error().decode())
+    return buf.value.decode()
+
+
+_KEY_DTYPES = {"uint32": (4, 0), "int32": (4, 1), "uint64": (8, 0), "int64": (8, 1)}
+
+
+class Engine:
+    """One device + one stream + one buffer set: the C-ABI `rsx_engine`."""
+
+    def __init__(self, dtype, capacity: int, payload: bool = False, device: int = 0):
+        self.lib = load_library()
+        self.dtype = np.dtype(dtype)
+        if self.dtype.name not in _KEY_DTYPES:
+            raise TypeError(f"unsupported key type {self.dtype}")
+        kb, sg = _KEY_DTYPES[self.dtype.name]
+        self.payload = bool(payload)
+        self.capacity = int(capacity)
+        self._h = C.c_void_p()
+        rc = self.lib.rsx_create(C.byref(self._h), device, kb, sg, int(self.payload), self.capacity)
+        if rc != 0:
+            raise RadixSortError(rc, "rsx_create", self.lib.rsx_last_error().decode())
+
+    # -- plumbing ----------------------------------------------------------
+    def _check(self, rc: int, where: str) -> None:
+        if rc != 0:
+            raise RadixSortError(rc, where, self.lib.rsx_last_error().decode())
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.rsx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_stream(self, hip_stream: int) -> None:
+        self._check(self.lib.rsx_set_stream(self._h, C.c_void_p(hip_stream)), "rsx_set_stream")
+
+    def set_option(self, option: int, value: int) -> None:
+        self._check(self.lib.rsx_set_option(self._h, option, value), "rsx_set_option")
+
+    def geometry(self) -> Geometry:
+        g = Geometry()
+        self._check(self.lib.rsx_get_geometry(self._h, C.byref(g)), "rsx_get_geometry")
+        return g
+
+    # -- reference-shaped steps ---------------------------------------------
+    def resize(self, n: int) -> None:
+        self._check(self.lib.rsx_resize(self._h, n), "rsx_resize")
+
+    def upload(self, keys: np.ndarray, perm: np.ndarray | None = None) -> None:
+        k = np.ascontiguousarray(keys, dtype=self.dtype)
+        p = None if perm is None else np.ascontiguousarray(perm, dtype=np.uint32)
+        self._check(self.lib.rsx_upload(self._h, k.ctypes.data, p.ctypes.data if p is not None else None, k.size), "rsx_upload")
+
+    def fill_pad(self, byte_offset: int) -> None:
+        self._check(self.lib.rsx_fill_pad(self._h, byte_offset), "rsx_fill_pad")
+
+    def histogram(self, pass_: int) -> None:
+        self._check(self.lib.rsx_histogram(self._h, pass_), "rsx_histogram")
+
+    def scan(self) -> None:
+        self._check(self.lib.rsx_scan(self._h), "rsx_scan")
+
+    def paste(self) -> None:
+        self._check(self.lib.rsx_paste(self._h), "rsx_paste")
+
+    def reorder(self, pass_: int) -> None:
+        self._check(self.lib.rsx_reorder(self._h, pass_), "rsx_reorder")
+
+    def sort(self) -> None:
+        self._check(self.lib.rsx_sort(self._h), "rsx_sort")
+
+    def sync(self) -> None:
+        self._check(self.lib.rsx_sync(self._h), "rsx_sync")
+
+    def download(self, want_perm: bool = False, hist_cap: int = 0, globsum_cap: int = 0):
+        n = self.geometry().num_keys
+        keys = np.empty(n, dtype=self.dtype)
+        perm = np.empty(n, dtype=np.uint32) if (want_perm and self.payload) else None
+        hist = np.zeros(hist_cap, dtype=np.uint32) if hist_cap else None
+        gs = np.zeros(globsum_cap, dtype=np.uint32) if globsum_cap else None
+        self._check(self.lib.rsx_download(
+            self._h, keys.ctypes.data, perm.ctypes.data if perm is not None else None,
+            hist.ctypes.data if hist is not None else None, hist_cap,
+            gs.ctypes.data if gs is not None else None, globsum_cap), "rsx_download")
+        out = [keys]
+        if want_perm:
+            out.append(perm)
+        if hist_cap:
+            out.append(hist)
+        if globsum_cap:
+            out.append(gs)
+        return out[0] if len(out) == 1 else tuple(out)
+
+    # -- device-resident callers ----------------------------------------------
+    def sort_from(self, d_keys: int, n: int, d_payload: int | None = None) -> None:
+        self._check(self.lib.rsx_sort_from(self._h, C.c_void_p(d_keys), C.c_void_p(d_payload) if d_payload else None, n), "rsx_sort_from")
+
+    def partition(self, d_keys: int, n: int, shift: int, bits: int, d_keys_out: int,
+                  d_payload: int | None = None, d_payload_out: int | None = None) -> list[int]:
+        offs = (C.c_uint64 * ((1 << bits) + 1))()
+        self._check(self.lib.rsx_partition(
+            self._h, C.c_void_p(d_keys), C.c_void_p(d_payload) if d_payload else None, n, shift, bits,
+            C.c_void_p(d_keys_out), C.c_void_p(d_payload_out) if d_payload_out else None, offs), "rsx_partition")
+        return [int(v) for v in offs]
+
+    def result_device(self) -> tuple[int, int]:
+        k, p = C.c_void_p(), C.c_void_p()
+        self._check(self.lib.rsx_result_device(self._h, C.byref(k), C.byref(p)), "rsx_result_device")
+        return int(k.value or 0), int(p.value or 0)
+
+    def copy_result(self, d_keys_out: int, d_payload_out: int | None = None) -> None:
+        self._check(self.lib.rsx_copy_result(self._h, C.c_void_p(d_keys_out), C.c_void_p(d_payload_out) if d_payload_out else None), "rsx_copy_result")
+
+    def timings(self, reset: bool = False) -> Runtimes:
+        r = Runtimes()
+        self._check(self.lib.rsx_timings(self._h, C.byref(r), int(reset)), "rsx_timings")
+        return r
+
+
+def sort_host(keys: np.ndarray, payload: np.ndarray | None = None, device: int = 0):
+    """upload -> sort -> download of a host array (the shape of ExecuteTask,
+    reference src/CRadixSortTask.cpp:289-314).  Returns sorted keys (and payload)."""
+    k = np.ascontiguousarray(keys)
+    with Engine(k.dtype, max(k.size, 1), payload=payload is not None, device=device) as e:
+        e.upload(k, payload)
+        e.sort()
+        if payload is None:
+            return e.download()
+        return e.download(want_perm=True)

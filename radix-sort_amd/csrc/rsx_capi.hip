@@ -1,0 +1,727 @@
+// rsx_capi.hip — implementation of include/radixsort_hip.h for gfx950.
+//
+// The engine owns what ComputeDeviceData<T> owns in the reference
+// (/root/reference/src/ComputeDeviceData.cpp:42-77): inputKeys/outputKeys,
+// inputPermutations/outputPermutations, histograms, globsum, temp — and drives the
+// kernels of rsx_kernels.hpp the way RadixSortGPU<T>::Histogram / ScanHistogram /
+// Reorder / calculate do (src/RadixSortGPU.cpp:16-346), minus the per-launch
+// `finish()`: everything is enqueued on one HIP stream and the host synchronises
+// only in upload/download/timings, as the C ABI header states.
+#include "radixsort_hip.h"
+#include "rsx_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int status, const char* what, hipError_t err = hipSuccess)
+{
+    g_last_error = what;
+    if (err != hipSuccess) {
+        g_last_error += ": ";
+        g_last_error += hipGetErrorString(err);
+    }
+    std::fprintf(stderr, "[radixsort_hip] %s\n", g_last_error.c_str());
+    return status;
+}
+
+#define RSX_TRY(expr, status)                                     \
+    do {                                                          \
+        const hipError_t rsx_err_ = (expr);                       \
+        if (rsx_err_ != hipSuccess) {                             \
+            return fail((status), #expr, rsx_err_);               \
+        }                                                         \
+    } while (0)
+
+// Tile geometry.  One compiled shape per key width for now; the table layout
+// depends on it, so it is fixed per engine.
+constexpr int kTileThreads = 256;
+constexpr int kKeysPerThread = 16;
+constexpr int kTileKeys = kTileThreads * kKeysPerThread;
+
+enum Phase : int { PH_HISTO = 0, PH_SCAN = 1, PH_PASTE = 2, PH_REORDER = 3, PH_TOTAL = 4, PH_COUNT = 5 };
+
+struct EventPair {
+    int phase;
+    hipEvent_t start, stop;
+};
+
+void stat_reset(rsx_phase_stat& s)
+{
+    s.min_ms = std::numeric_limits<double>::infinity();
+    s.max_ms = -std::numeric_limits<double>::infinity();
+    s.avg_ms = 0.0;
+    s.sum_ms = 0.0;
+    s.n = 0;
+}
+
+// Statistics::update (src/Statistics.h:21-31) with the first-sample-min slip fixed:
+// the reference's `else if` never lets the first sample become the minimum.
+void stat_update(rsx_phase_stat& s, double ms)
+{
+    s.n += 1;
+    s.sum_ms += ms;
+    s.avg_ms = s.sum_ms / static_cast<double>(s.n);
+    s.max_ms = std::max(s.max_ms, ms);
+    s.min_ms = std::min(s.min_ms, ms);
+}
+
+}  // namespace
+
+struct rsx_engine {
+    int device = 0;
+    int key_bytes = 4;
+    bool is_signed = false;
+    bool has_payload = false;
+    uint64_t capacity = 0;
+    uint64_t n = 0;
+
+    void* keys[2] = {nullptr, nullptr};         // [cur] = "inputKeys", [cur^1] = "outputKeys"
+    uint32_t* perm[2] = {nullptr, nullptr};     // inputPermutations / outputPermutations
+    int cur = 0;
+    // where the sorted data of the last rsx_sort / rsx_sort_from lives
+    void* result_keys = nullptr;
+    uint32_t* result_perm = nullptr;
+
+    uint32_t* table = nullptr;                  // "histograms": [digit][tile]
+    uint32_t* globsum = nullptr;                // block sums of the table scan
+    uint32_t* temp = nullptr;                   // grand total of scan #2
+    uint32_t* starts_dev = nullptr;             // 16 bucket starts (rsx_partition)
+    uint32_t* starts_host = nullptr;            // pinned mirror
+    uint64_t table_cap = 0;
+
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+
+    bool profile = false;
+    int xcd_remap = 1;
+    int first_pass = 0;
+    int last_pass = 0;
+
+    std::vector<EventPair> pending;
+    std::vector<hipEvent_t> pool;
+    rsx_phase_stat stats[PH_COUNT];
+
+    uint32_t passes() const { return static_cast<uint32_t>(key_bytes * 8 / RSX_RADIX_BITS); }
+    uint64_t ntiles(uint64_t count) const { return (count + kTileKeys - 1) / kTileKeys; }
+};
+
+namespace {
+
+struct Bracket {   // optional HIP-event pair around one launch (profile mode)
+    rsx_engine* e;
+    int phase;
+    hipEvent_t start = nullptr, stop = nullptr;
+    bool on = false;
+    Bracket(rsx_engine* eng, int ph) : e(eng), phase(ph)
+    {
+        if (!e->profile) return;
+        auto take = [&]() -> hipEvent_t {
+            if (!e->pool.empty()) {
+                hipEvent_t ev = e->pool.back();
+                e->pool.pop_back();
+                return ev;
+            }
+            hipEvent_t ev = nullptr;
+            if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+            return ev;
+        };
+        start = take();
+        stop = take();
+        on = start && stop;
+        if (on) (void)hipEventRecord(start, e->stream);
+    }
+    ~Bracket()
+    {
+        if (!on) return;
+        (void)hipEventRecord(stop, e->stream);
+        e->pending.push_back({phase, start, stop});
+    }
+};
+
+int drain_events(rsx_engine* e)
+{
+    RSX_TRY(hipStreamSynchronize(e->stream), RSX_CALCULATION_FAILED);
+    for (const EventPair& p : e->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {
+            stat_update(e->stats[p.phase], static_cast<double>(ms));
+        }
+        e->pool.push_back(p.start);
+        e->pool.push_back(p.stop);
+    }
+    e->pending.clear();
+    return RSX_OK;
+}
+
+template <typename Key>
+Key flip_mask(const rsx_engine* e)
+{
+    return e->is_signed ? static_cast<Key>(Key{1} << (sizeof(Key) * 8 - 1)) : Key{0};
+}
+
+struct Grid {
+    uint32_t ntiles, tiles_per_xcd, blocks;
+};
+
+Grid grid_for(const rsx_engine* e, uint64_t count)
+{
+    Grid g;
+    g.ntiles = static_cast<uint32_t>(e->ntiles(count));
+    g.tiles_per_xcd = (g.ntiles + rsx::kNumXcd - 1) / rsx::kNumXcd;
+    g.blocks = e->xcd_remap ? g.tiles_per_xcd * rsx::kNumXcd : g.ntiles;
+    return g;
+}
+
+template <typename Key>
+int launch_histogram(rsx_engine* e, const void* in, uint64_t count, int shift, uint32_t mask)
+{
+    if (count == 0) return RSX_OK;
+    const Grid g = grid_for(e, count);
+    Bracket b(e, PH_HISTO);
+    hipLaunchKernelGGL((rsx::histogram_kernel<Key, kTileThreads, kKeysPerThread>), dim3(g.blocks), dim3(kTileThreads), 0, e->stream,
+                       static_cast<const Key*>(in), e->table, count, g.ntiles, g.tiles_per_xcd, e->xcd_remap, shift,
+                       flip_mask<Key>(e), mask);
+    RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
+    return RSX_OK;
+}
+
+int launch_scan(rsx_engine* e, uint64_t count)
+{
+    if (count == 0) return RSX_OK;
+    const uint64_t len = static_cast<uint64_t>(RSX_RADIX) * e->ntiles(count);
+    const uint32_t nblocks = static_cast<uint32_t>((len + rsx::kScanBlock - 1) / rsx::kScanBlock);
+    {
+        Bracket b(e, PH_SCAN);
+        hipLaunchKernelGGL(rsx::scan_blocks_kernel, dim3(nblocks), dim3(rsx::kScanThreads), 0, e->stream, e->table, e->globsum, len);
+    }
+    RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
+    {
+        Bracket b(e, PH_SCAN);
+        hipLaunchKernelGGL(rsx::scan_globsum_kernel, dim3(1), dim3(rsx::kGlobsumThreads), 0, e->stream, e->globsum, e->temp, nblocks);
+    }
+    RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
+    return RSX_OK;
+}
+
+int launch_paste(rsx_engine* e, uint64_t count)
+{
+    if (count == 0) return RSX_OK;
+    const uint64_t len = static_cast<uint64_t>(RSX_RADIX) * e->ntiles(count);
+    const uint32_t nblocks = static_cast<uint32_t>((len + rsx::kScanBlock - 1) / rsx::kScanBlock);
+    Bracket b(e, PH_PASTE);
+    hipLaunchKernelGGL(rsx::paste_kernel, dim3(nblocks), dim3(rsx::kScanThreads), 0, e->stream, e->table, e->globsum, len);
+    RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
+    return RSX_OK;
+}
+
+template <typename Key, bool PAYLOAD>
+int launch_reorder_t(rsx_engine* e, const void* in, void* out, const uint32_t* pin, uint32_t* pout, uint64_t count, int shift,
+                     uint32_t mask)
+{
+    using L = rsx::ReorderLayout<Key, kTileThreads, kKeysPerThread>;
+    const Grid g = grid_for(e, count);
+    Bracket b(e, PH_REORDER);
+    hipLaunchKernelGGL((rsx::reorder_kernel<Key, kTileThreads, kKeysPerThread, PAYLOAD>), dim3(g.blocks), dim3(kTileThreads),
+                       L::BYTES, e->stream, static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->table, count,
+                       g.ntiles, g.tiles_per_xcd, e->xcd_remap, shift, flip_mask<Key>(e), mask);
+    RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
+    return RSX_OK;
+}
+
+template <typename Key>
+int launch_reorder(rsx_engine* e, const void* in, void* out, const uint32_t* pin, uint32_t* pout, uint64_t count, int shift,
+                   uint32_t mask)
+{
+    if (count == 0) return RSX_OK;
+    if (pin && pout) {
+        return launch_reorder_t<Key, true>(e, in, out, pin, pout, count, shift, mask);
+    }
+    return launch_reorder_t<Key, false>(e, in, out, nullptr, nullptr, count, shift, mask);
+}
+
+template <typename Key, bool PAYLOAD>
+int allow_lds()
+{
+    using L = rsx::ReorderLayout<Key, kTileThreads, kKeysPerThread>;
+    RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder_kernel<Key, kTileThreads, kKeysPerThread, PAYLOAD>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L::BYTES)),
+            RSX_INITIALIZATION_FAILED);
+    return RSX_OK;
+}
+
+// One full pass chain on explicit buffers: histogram -> scan -> paste -> reorder.
+template <typename Key>
+int run_pass(rsx_engine* e, const void* in, void* out, const uint32_t* pin, uint32_t* pout, uint64_t count, int shift, uint32_t mask)
+{
+    int rc;
+    if ((rc = launch_histogram<Key>(e, in, count, shift, mask)) != RSX_OK) return rc;
+    if ((rc = launch_scan(e, count)) != RSX_OK) return rc;
+    if ((rc = launch_paste(e, count)) != RSX_OK) return rc;
+    return launch_reorder<Key>(e, in, out, pin, pout, count, shift, mask);
+}
+
+template <typename Key>
+int sort_chain(rsx_engine* e, const void* ext_keys, const uint32_t* ext_perm, uint64_t count)
+{
+    // Ping-pong.  With external input the first pass reads the caller's buffer (never
+    // written) and the chain continues inside the engine's two buffers.
+    const void* in = ext_keys ? ext_keys : e->keys[e->cur];
+    const uint32_t* pin = e->has_payload ? (ext_keys ? ext_perm : e->perm[e->cur]) : nullptr;
+    int dst = ext_keys ? e->cur : (e->cur ^ 1);
+    Bracket whole(e, PH_TOTAL);
+    for (int pass = e->first_pass; pass < e->last_pass; ++pass) {
+        void* out = e->keys[dst];
+        uint32_t* pout = e->has_payload ? e->perm[dst] : nullptr;
+        const int rc = run_pass<Key>(e, in, out, pin, pout, count, pass * RSX_RADIX_BITS, RSX_RADIX - 1);
+        if (rc != RSX_OK) return rc;
+        in = out;
+        pin = pout;
+        dst ^= 1;
+    }
+    // `in` now names the buffer holding the result; make it the engine's "inputKeys"
+    // (the reference's even pass count guarantees the same, src/RadixSortGPU.cpp:263-266,394-400)
+    if (in == e->keys[0] || in == e->keys[1]) {
+        e->cur = (in == e->keys[0]) ? 0 : 1;
+    }
+    e->result_keys = e->keys[e->cur];
+    e->result_perm = e->has_payload ? e->perm[e->cur] : nullptr;
+    return RSX_OK;
+}
+
+bool aligned16(const void* p)
+{
+    return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
+}
+
+int bind_device(const rsx_engine* e, int status)
+{
+    RSX_TRY(hipSetDevice(e->device), status);
+    return RSX_OK;
+}
+
+}  // namespace
+
+#define RSX_BY_KEY(e, call32, call64) ((e)->key_bytes == 4 ? (call32) : (call64))
+
+extern "C" {
+
+const char* rsx_last_error(void)
+{
+    return g_last_error.c_str();
+}
+
+const char* rsx_version(void)
+{
+    return "radixsort_hip 0.1 (gfx950; tile 256x16; 4-bit LSD)";
+}
+
+int rsx_device_count(int* count)
+{
+    if (!count) return fail(RSX_INITIALIZATION_FAILED, "rsx_device_count: null argument");
+    *count = 0;
+    int c = 0;
+    const hipError_t err = hipGetDeviceCount(&c);
+    if (err != hipSuccess) {
+        return fail(RSX_INITIALIZATION_FAILED, "hipGetDeviceCount", err);
+    }
+    *count = c;
+    return RSX_OK;
+}
+
+int rsx_device_name(int device, char* buf, size_t buflen)
+{
+    if (!buf || buflen == 0) return fail(RSX_INITIALIZATION_FAILED, "rsx_device_name: null buffer");
+    hipDeviceProp_t prop;
+    RSX_TRY(hipGetDeviceProperties(&prop, device), RSX_INITIALIZATION_FAILED);
+    std::snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return RSX_OK;
+}
+
+int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int has_payload, uint64_t capacity)
+{
+    if (!out) return fail(RSX_INITIALIZATION_FAILED, "rsx_create: null out pointer");
+    *out = nullptr;
+    if (key_bytes != 4 && key_bytes != 8) return fail(RSX_INITIALIZATION_FAILED, "rsx_create: key_bytes must be 4 or 8");
+    if (capacity == 0 || capacity > 0xFFFFFFFFull) {
+        return fail(RSX_RESIZE_FAILED, "rsx_create: capacity must be in [1, 2^32-1] (32-bit slots)");
+    }
+    int count = 0;
+    if (rsx_device_count(&count) != RSX_OK || count <= 0) {
+        return fail(RSX_INITIALIZATION_FAILED, "rsx_create: no HIP device (this library has no CPU fallback)");
+    }
+    if (device < 0 || device >= count) return fail(RSX_INITIALIZATION_FAILED, "rsx_create: device ordinal out of range");
+
+    rsx_engine* e = new (std::nothrow) rsx_engine();
+    if (!e) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_create: out of host memory");
+    e->device = device;
+    e->key_bytes = key_bytes;
+    e->is_signed = is_signed != 0;
+    e->has_payload = has_payload != 0;
+    e->capacity = capacity;
+    e->n = 0;
+    e->last_pass = static_cast<int>(e->passes());
+    for (auto& s : e->stats) stat_reset(s);
+    if (const char* env = std::getenv("RSX_XCD_REMAP")) e->xcd_remap = std::atoi(env) != 0;
+
+    auto bail = [&](int status, const char* what, hipError_t err) {
+        rsx_destroy(e);
+        return fail(status, what, err);
+    };
+    hipError_t err;
+    if ((err = hipSetDevice(device)) != hipSuccess) return bail(RSX_INITIALIZATION_FAILED, "hipSetDevice", err);
+    if ((err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess)
+        return bail(RSX_INITIALIZATION_FAILED, "hipStreamCreate", err);
+    e->own_stream = true;
+
+    const size_t key_buf = static_cast<size_t>(capacity) * key_bytes;
+    for (int i = 0; i < 2; ++i) {
+        if ((err = hipMalloc(&e->keys[i], key_buf)) != hipSuccess) return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(keys)", err);
+        if (e->has_payload) {
+            if ((err = hipMalloc(reinterpret_cast<void**>(&e->perm[i]), static_cast<size_t>(capacity) * 4)) != hipSuccess)
+                return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(permutations)", err);
+        }
+    }
+    e->table_cap = static_cast<uint64_t>(RSX_RADIX) * e->ntiles(capacity);
+    if ((e->table_cap + rsx::kScanBlock - 1) / rsx::kScanBlock > rsx::kMaxScanBlocks) {
+        return bail(RSX_RESIZE_FAILED, "rsx_create: capacity exceeds the two-level table scan", hipSuccess);
+    }
+    // table rounded up to whole scan blocks so vector accesses of the tail stay in bounds
+    const size_t table_alloc = ((e->table_cap + rsx::kScanBlock - 1) / rsx::kScanBlock) * rsx::kScanBlock * 4;
+    if ((err = hipMalloc(reinterpret_cast<void**>(&e->table), table_alloc)) != hipSuccess)
+        return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(histograms)", err);
+    if ((err = hipMalloc(reinterpret_cast<void**>(&e->globsum), rsx::kMaxScanBlocks * 4)) != hipSuccess)
+        return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(globsum)", err);
+    if ((err = hipMalloc(reinterpret_cast<void**>(&e->temp), 64)) != hipSuccess)
+        return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(temp)", err);
+    if ((err = hipMalloc(reinterpret_cast<void**>(&e->starts_dev), RSX_RADIX * 4)) != hipSuccess)
+        return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(starts)", err);
+    if ((err = hipHostMalloc(reinterpret_cast<void**>(&e->starts_host), RSX_RADIX * 4, hipHostMallocDefault)) != hipSuccess)
+        return bail(RSX_HOST_BUFFERS_FAILED, "hipHostMalloc(starts)", err);
+    if ((err = hipMemsetAsync(e->globsum, 0, rsx::kMaxScanBlocks * 4, e->stream)) != hipSuccess)
+        return bail(RSX_INITIALIZATION_FAILED, "hipMemsetAsync(globsum)", err);
+
+    int rc = RSX_OK;
+    if (rc == RSX_OK) rc = allow_lds<uint32_t, false>();
+    if (rc == RSX_OK) rc = allow_lds<uint32_t, true>();
+    if (rc == RSX_OK) rc = allow_lds<uint64_t, false>();
+    if (rc == RSX_OK) rc = allow_lds<uint64_t, true>();
+    if (rc != RSX_OK) {
+        rsx_destroy(e);
+        return rc;
+    }
+    e->result_keys = e->keys[0];
+    e->result_perm = e->perm[0];
+    *out = e;
+    return RSX_OK;
+}
+
+int rsx_destroy(rsx_engine* e)
+{
+    if (!e) return RSX_OK;
+    int status = RSX_OK;
+    if (hipSetDevice(e->device) != hipSuccess) status = RSX_CLEANUP_FAILED;
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (const EventPair& p : e->pending) {
+        (void)hipEventDestroy(p.start);
+        (void)hipEventDestroy(p.stop);
+    }
+    for (hipEvent_t ev : e->pool) (void)hipEventDestroy(ev);
+    for (int i = 0; i < 2; ++i) {
+        if (e->keys[i] && hipFree(e->keys[i]) != hipSuccess) status = RSX_CLEANUP_FAILED;
+        if (e->perm[i] && hipFree(e->perm[i]) != hipSuccess) status = RSX_CLEANUP_FAILED;
+    }
+    if (e->table && hipFree(e->table) != hipSuccess) status = RSX_CLEANUP_FAILED;
+    if (e->globsum && hipFree(e->globsum) != hipSuccess) status = RSX_CLEANUP_FAILED;
+    if (e->temp && hipFree(e->temp) != hipSuccess) status = RSX_CLEANUP_FAILED;
+    if (e->starts_dev && hipFree(e->starts_dev) != hipSuccess) status = RSX_CLEANUP_FAILED;
+    if (e->starts_host && hipHostFree(e->starts_host) != hipSuccess) status = RSX_CLEANUP_FAILED;
+    if (e->own_stream && e->stream && hipStreamDestroy(e->stream) != hipSuccess) status = RSX_CLEANUP_FAILED;
+    delete e;
+    return status;
+}
+
+int rsx_set_stream(rsx_engine* e, void* hip_stream)
+{
+    if (!e) return fail(RSX_INITIALIZATION_FAILED, "rsx_set_stream: null engine");
+    if (bind_device(e, RSX_INITIALIZATION_FAILED) != RSX_OK) return RSX_INITIALIZATION_FAILED;
+    const int rc = drain_events(e);
+    if (rc != RSX_OK) return rc;
+    if (e->own_stream && e->stream) {
+        RSX_TRY(hipStreamDestroy(e->stream), RSX_INITIALIZATION_FAILED);
+    }
+    e->stream = static_cast<hipStream_t>(hip_stream);
+    e->own_stream = false;
+    return RSX_OK;
+}
+
+int rsx_set_option(rsx_engine* e, int option, int64_t value)
+{
+    if (!e) return fail(RSX_INITIALIZATION_FAILED, "rsx_set_option: null engine");
+    switch (option) {
+    case RSX_OPT_PROFILE: e->profile = value != 0; return RSX_OK;
+    case RSX_OPT_XCD_REMAP: e->xcd_remap = value != 0; return RSX_OK;
+    case RSX_OPT_FIRST_PASS:
+        if (value < 0 || value > e->passes()) return fail(RSX_CALCULATION_FAILED, "rsx_set_option: first pass out of range");
+        e->first_pass = static_cast<int>(value);
+        return RSX_OK;
+    case RSX_OPT_LAST_PASS:
+        if (value < 0 || value > e->passes()) return fail(RSX_CALCULATION_FAILED, "rsx_set_option: last pass out of range");
+        e->last_pass = static_cast<int>(value);
+        return RSX_OK;
+    default: return fail(RSX_INITIALIZATION_FAILED, "rsx_set_option: unknown option");
+    }
+}
+
+int rsx_get_geometry(const rsx_engine* e, rsx_geometry* out)
+{
+    if (!e || !out) return fail(RSX_INITIALIZATION_FAILED, "rsx_get_geometry: null argument");
+    out->tile_threads = kTileThreads;
+    out->keys_per_thread = kKeysPerThread;
+    out->tile_keys = kTileKeys;
+    out->scan_block = rsx::kScanBlock;
+    out->num_keys = e->n;
+    out->capacity = e->capacity;
+    out->num_tiles = e->ntiles(e->n);
+    out->table_len = static_cast<uint64_t>(RSX_RADIX) * out->num_tiles;
+    out->num_scan_blocks = (out->table_len + rsx::kScanBlock - 1) / rsx::kScanBlock;
+    out->num_passes = e->passes();
+    out->key_bytes = static_cast<uint32_t>(e->key_bytes);
+    return RSX_OK;
+}
+
+int rsx_resize(rsx_engine* e, uint64_t num_keys)
+{
+    if (!e) return fail(RSX_RESIZE_FAILED, "rsx_resize: null engine");
+    if (num_keys > e->capacity) return fail(RSX_RESIZE_FAILED, "rsx_resize: beyond capacity");
+    e->n = num_keys;
+    return RSX_OK;
+}
+
+int rsx_upload(rsx_engine* e, const void* host_keys, const uint32_t* host_perm, uint64_t n)
+{
+    if (!e) return fail(RSX_DATA_UPLOAD_FAILED, "rsx_upload: null engine");
+    if (n > e->capacity) return fail(RSX_DATA_UPLOAD_FAILED, "rsx_upload: beyond capacity");
+    if (n > 0 && !host_keys) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_upload: null host keys");
+    if (bind_device(e, RSX_DATA_UPLOAD_FAILED) != RSX_OK) return RSX_DATA_UPLOAD_FAILED;
+    e->n = n;
+    if (n > 0) {
+        RSX_TRY(hipMemcpyAsync(e->keys[e->cur], host_keys, static_cast<size_t>(n) * e->key_bytes, hipMemcpyHostToDevice, e->stream),
+                RSX_DATA_UPLOAD_FAILED);
+        if (e->has_payload) {
+            if (!host_perm) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_upload: payload engine needs a permutation buffer");
+            RSX_TRY(hipMemcpyAsync(e->perm[e->cur], host_perm, static_cast<size_t>(n) * 4, hipMemcpyHostToDevice, e->stream),
+                    RSX_DATA_UPLOAD_FAILED);
+        }
+    }
+    RSX_TRY(hipStreamSynchronize(e->stream), RSX_DATA_UPLOAD_FAILED);   // "wait until end of write" (RadixSortGPU.cpp:305)
+    e->result_keys = e->keys[e->cur];
+    e->result_perm = e->has_payload ? e->perm[e->cur] : nullptr;
+    return RSX_OK;
+}
+
+int rsx_fill_pad(rsx_engine* e, uint64_t byte_offset)
+{
+    if (!e) return fail(RSX_CALCULATION_FAILED, "rsx_fill_pad: null engine");
+    const uint64_t first = byte_offset / e->key_bytes;
+    if (byte_offset % e->key_bytes != 0 || first > e->n) return fail(RSX_CALCULATION_FAILED, "rsx_fill_pad: bad offset");
+    const uint64_t count = e->n - first;
+    if (count == 0) return RSX_OK;
+    if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
+    const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((count + 255) / 256, 2048));
+    if (e->key_bytes == 4) {
+        // numeric_limits<T>::max() - 1 (RadixSortGPU.cpp:274-276)
+        const uint32_t v = e->is_signed ? 0x7FFFFFFEu : 0xFFFFFFFEu;
+        hipLaunchKernelGGL(rsx::fill_kernel<uint32_t>, dim3(blocks), dim3(256), 0, e->stream, static_cast<uint32_t*>(e->keys[e->cur]),
+                           first, count, v);
+    } else {
+        const uint64_t v = e->is_signed ? 0x7FFFFFFFFFFFFFFEull : 0xFFFFFFFFFFFFFFFEull;
+        hipLaunchKernelGGL(rsx::fill_kernel<uint64_t>, dim3(blocks), dim3(256), 0, e->stream, static_cast<uint64_t*>(e->keys[e->cur]),
+                           first, count, v);
+    }
+    RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
+    return RSX_OK;
+}
+
+int rsx_download(rsx_engine* e, void* host_keys_out, uint32_t* host_perm_out, uint32_t* hist_out, uint64_t hist_cap,
+                 uint32_t* globsum_out, uint64_t globsum_cap)
+{
+    if (!e) return fail(RSX_DATA_DOWNLOAD_FAILED, "rsx_download: null engine");
+    if (bind_device(e, RSX_DATA_DOWNLOAD_FAILED) != RSX_OK) return RSX_DATA_DOWNLOAD_FAILED;
+    if (e->n > 0 && host_keys_out) {
+        RSX_TRY(hipMemcpyAsync(host_keys_out, e->result_keys, static_cast<size_t>(e->n) * e->key_bytes, hipMemcpyDeviceToHost, e->stream),
+                RSX_DATA_DOWNLOAD_FAILED);
+    }
+    if (e->n > 0 && host_perm_out && e->has_payload) {
+        RSX_TRY(hipMemcpyAsync(host_perm_out, e->result_perm, static_cast<size_t>(e->n) * 4, hipMemcpyDeviceToHost, e->stream),
+                RSX_DATA_DOWNLOAD_FAILED);
+    }
+    if (hist_out && hist_cap) {
+        const uint64_t live = static_cast<uint64_t>(RSX_RADIX) * e->ntiles(e->n);
+        const uint64_t take = std::min(hist_cap, live);
+        if (take) {
+            RSX_TRY(hipMemcpyAsync(hist_out, e->table, take * 4, hipMemcpyDeviceToHost, e->stream), RSX_DATA_DOWNLOAD_FAILED);
+        }
+    }
+    if (globsum_out && globsum_cap) {
+        const uint64_t take = std::min<uint64_t>(globsum_cap, rsx::kMaxScanBlocks);
+        RSX_TRY(hipMemcpyAsync(globsum_out, e->globsum, take * 4, hipMemcpyDeviceToHost, e->stream), RSX_DATA_DOWNLOAD_FAILED);
+    }
+    RSX_TRY(hipStreamSynchronize(e->stream), RSX_DATA_DOWNLOAD_FAILED);
+    return RSX_OK;
+}
+
+int rsx_histogram(rsx_engine* e, int pass)
+{
+    if (!e) return fail(RSX_CALCULATION_FAILED, "rsx_histogram: null engine");
+    if (pass < 0 || pass >= static_cast<int>(e->passes())) return fail(RSX_CALCULATION_FAILED, "rsx_histogram: pass out of range");
+    if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
+    return RSX_BY_KEY(e, launch_histogram<uint32_t>(e, e->keys[e->cur], e->n, pass * RSX_RADIX_BITS, RSX_RADIX - 1),
+                      launch_histogram<uint64_t>(e, e->keys[e->cur], e->n, pass * RSX_RADIX_BITS, RSX_RADIX - 1));
+}
+
+int rsx_scan(rsx_engine* e)
+{
+    if (!e) return fail(RSX_CALCULATION_FAILED, "rsx_scan: null engine");
+    if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
+    return launch_scan(e, e->n);
+}
+
+int rsx_paste(rsx_engine* e)
+{
+    if (!e) return fail(RSX_CALCULATION_FAILED, "rsx_paste: null engine");
+    if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
+    return launch_paste(e, e->n);
+}
+
+int rsx_reorder(rsx_engine* e, int pass)
+{
+    if (!e) return fail(RSX_CALCULATION_FAILED, "rsx_reorder: null engine");
+    if (pass < 0 || pass >= static_cast<int>(e->passes())) return fail(RSX_CALCULATION_FAILED, "rsx_reorder: pass out of range");
+    if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
+    const int src = e->cur, dst = e->cur ^ 1;
+    const uint32_t* pin = e->has_payload ? e->perm[src] : nullptr;
+    uint32_t* pout = e->has_payload ? e->perm[dst] : nullptr;
+    const int rc = RSX_BY_KEY(e, launch_reorder<uint32_t>(e, e->keys[src], e->keys[dst], pin, pout, e->n, pass * RSX_RADIX_BITS, RSX_RADIX - 1),
+                              launch_reorder<uint64_t>(e, e->keys[src], e->keys[dst], pin, pout, e->n, pass * RSX_RADIX_BITS, RSX_RADIX - 1));
+    if (rc != RSX_OK) return rc;
+    e->cur = dst;   // swap of the buffer names (RadixSortGPU.cpp:263-266)
+    e->result_keys = e->keys[e->cur];
+    e->result_perm = e->has_payload ? e->perm[e->cur] : nullptr;
+    return RSX_OK;
+}
+
+int rsx_sort(rsx_engine* e)
+{
+    if (!e) return fail(RSX_CALCULATION_FAILED, "rsx_sort: null engine");
+    if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
+    return RSX_BY_KEY(e, sort_chain<uint32_t>(e, nullptr, nullptr, e->n), sort_chain<uint64_t>(e, nullptr, nullptr, e->n));
+}
+
+int rsx_sync(rsx_engine* e)
+{
+    if (!e) return fail(RSX_CALCULATION_FAILED, "rsx_sync: null engine");
+    if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
+    RSX_TRY(hipStreamSynchronize(e->stream), RSX_CALCULATION_FAILED);
+    return RSX_OK;
+}
+
+int rsx_sort_from(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n)
+{
+    if (!e) return fail(RSX_CALCULATION_FAILED, "rsx_sort_from: null engine");
+    if (n > e->capacity) return fail(RSX_RESIZE_FAILED, "rsx_sort_from: beyond capacity");
+    if (n > 0 && (!d_keys || !aligned16(d_keys))) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_sort_from: keys must be a 16-byte aligned device pointer");
+    if (e->has_payload && n > 0 && (!d_payload || !aligned16(d_payload)))
+        return fail(RSX_HOST_BUFFERS_FAILED, "rsx_sort_from: payload engine needs a 16-byte aligned payload pointer");
+    if (e->first_pass >= e->last_pass) return fail(RSX_CALCULATION_FAILED, "rsx_sort_from: empty pass range");
+    if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
+    e->n = n;
+    if (n == 0) return RSX_OK;
+    return RSX_BY_KEY(e, sort_chain<uint32_t>(e, d_keys, d_payload, n), sort_chain<uint64_t>(e, d_keys, d_payload, n));
+}
+
+int rsx_partition(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n, int shift, int bits, void* d_keys_out,
+                  uint32_t* d_payload_out, uint64_t* bucket_offsets)
+{
+    if (!e || !bucket_offsets) return fail(RSX_CALCULATION_FAILED, "rsx_partition: null argument");
+    if (bits < 0 || bits > RSX_RADIX_BITS || shift < 0 || shift + bits > e->key_bytes * 8)
+        return fail(RSX_CALCULATION_FAILED, "rsx_partition: bit field out of range (at most 4 bits)");
+    if (n > e->capacity) return fail(RSX_RESIZE_FAILED, "rsx_partition: beyond capacity");
+    const uint32_t buckets = 1u << bits;
+    if (n > 0 && (!d_keys || !d_keys_out || !aligned16(d_keys) || !aligned16(d_keys_out)))
+        return fail(RSX_HOST_BUFFERS_FAILED, "rsx_partition: key buffers must be 16-byte aligned device pointers");
+    const bool with_payload = e->has_payload && d_payload && d_payload_out;
+    if (e->has_payload && !with_payload && n > 0) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_partition: payload engine needs payload buffers");
+    if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
+    if (n == 0) {
+        for (uint32_t d = 0; d <= buckets; ++d) bucket_offsets[d] = 0;
+        return RSX_OK;
+    }
+    const uint32_t mask = buckets - 1;
+    const uint32_t* pin = with_payload ? d_payload : nullptr;
+    uint32_t* pout = with_payload ? d_payload_out : nullptr;
+    const int rc = RSX_BY_KEY(e, run_pass<uint32_t>(e, d_keys, d_keys_out, pin, pout, n, shift, mask),
+                              run_pass<uint64_t>(e, d_keys, d_keys_out, pin, pout, n, shift, mask));
+    if (rc != RSX_OK) return rc;
+    hipLaunchKernelGGL(rsx::bucket_starts_kernel, dim3(1), dim3(64), 0, e->stream, e->table, static_cast<uint32_t>(e->ntiles(n)), e->starts_dev);
+    RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
+    RSX_TRY(hipMemcpyAsync(e->starts_host, e->starts_dev, RSX_RADIX * 4, hipMemcpyDeviceToHost, e->stream), RSX_CALCULATION_FAILED);
+    RSX_TRY(hipStreamSynchronize(e->stream), RSX_CALCULATION_FAILED);
+    for (uint32_t d = 0; d < buckets; ++d) bucket_offsets[d] = e->starts_host[d];
+    bucket_offsets[buckets] = n;
+    return RSX_OK;
+}
+
+int rsx_result_device(rsx_engine* e, void** d_keys, uint32_t** d_payload)
+{
+    if (!e) return fail(RSX_CALCULATION_FAILED, "rsx_result_device: null engine");
+    if (d_keys) *d_keys = e->result_keys;
+    if (d_payload) *d_payload = e->result_perm;
+    return RSX_OK;
+}
+
+int rsx_copy_result(rsx_engine* e, void* d_keys_out, uint32_t* d_payload_out)
+{
+    if (!e) return fail(RSX_DATA_DOWNLOAD_FAILED, "rsx_copy_result: null engine");
+    if (bind_device(e, RSX_DATA_DOWNLOAD_FAILED) != RSX_OK) return RSX_DATA_DOWNLOAD_FAILED;
+    if (e->n == 0) return RSX_OK;
+    if (d_keys_out) {
+        RSX_TRY(hipMemcpyAsync(d_keys_out, e->result_keys, static_cast<size_t>(e->n) * e->key_bytes, hipMemcpyDeviceToDevice, e->stream),
+                RSX_DATA_DOWNLOAD_FAILED);
+    }
+    if (d_payload_out && e->has_payload) {
+        RSX_TRY(hipMemcpyAsync(d_payload_out, e->result_perm, static_cast<size_t>(e->n) * 4, hipMemcpyDeviceToDevice, e->stream),
+                RSX_DATA_DOWNLOAD_FAILED);
+    }
+    return RSX_OK;
+}
+
+int rsx_timings(rsx_engine* e, rsx_runtimes* out, int reset)
+{
+    if (!e || !out) return fail(RSX_CALCULATION_FAILED, "rsx_timings: null argument");
+    if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
+    const int rc = drain_events(e);
+    if (rc != RSX_OK) return rc;
+    out->histogram = e->stats[PH_HISTO];
+    out->scan = e->stats[PH_SCAN];
+    out->paste = e->stats[PH_PASTE];
+    out->reorder = e->stats[PH_REORDER];
+    out->total = e->stats[PH_TOTAL];
+    if (reset) {
+        for (auto& s : e->stats) stat_reset(s);
+    }
+    return RSX_OK;
+}
+
+}  // extern "C"

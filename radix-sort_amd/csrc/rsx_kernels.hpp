@@ -1,0 +1,545 @@
+// rsx_kernels.hpp — hand-written HIP kernels of the LSD radix sort for gfx950 (MI355X).
+//
+// Four device steps per 4-bit pass, the counterparts of the reference's OpenCL
+// kernels (/root/reference/src/kernels/RadixSort.cl):
+//
+//   histogram_kernel      <- `histogram`        (RadixSort.cl:16-71)
+//   scan_blocks_kernel    <- `scanhistograms` #1 (RadixSort.cl:125-181, RadixSortGPU.cpp:66-113)
+//   scan_globsum_kernel   <- `scanhistograms` #2 (RadixSortGPU.cpp:115-152)
+//   paste_kernel          <- `pastehistograms`   (RadixSort.cl:185-197)
+//   reorder_kernel        <- `reorder`           (RadixSort.cl:74-119)
+//
+// What is kept from the reference is the algorithmic contract only: the digit of a
+// key is `((key + OFFSET) >> (pass*4)) & 15`, the counter table is digit-major, its
+// global exclusive prefix sum gives the first output slot of every (digit, producer)
+// pair, and producers emit their keys in index order — hence a stable pass.
+//
+// What is different is everything that touches the machine.  The reference gives each
+// of 1024 work-items a contiguous n/1024 sub-list (no access is coalesced, 16
+// work-groups).  Here a *tile* of THREADS*KPT consecutive keys is one workgroup's
+// unit of work, the table is [digit][tile], and inside a tile the reference's idea is
+// replayed at LDS scale: THREADS "virtual processors" each own KPT consecutive keys and
+// 16 private 16-bit counters in LDS, a raking DPP scan over the [digit][thread]
+// counters yields every key's slot in the tile-local sorted order, keys are staged
+// through LDS in that order, and the tile leaves as (up to) 16 runs of consecutive
+// addresses.  HBM sees 16-byte/lane coalesced loads and run-coalesced stores.
+//
+// No MFMA: this is an integer permutation bounded by HBM bandwidth.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rsx {
+
+constexpr int kRadixBits = 4;
+constexpr int kRadix = 1 << kRadixBits;
+constexpr int kWave = 64;      // CDNA wavefront
+constexpr int kNumXcd = 8;     // MI355X: 8 XCDs, each with a private L2
+
+// ---------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------
+
+// 16-byte vector of keys: 4 x u32 or 2 x u64 -> one global_load_dwordx4 / ds_*_b128.
+template <typename Key>
+struct alignas(16) KeyVec {
+    static constexpr int N = 16 / sizeof(Key);
+    Key k[N];
+};
+
+struct alignas(16) U32x4 {
+    uint32_t v[4];
+};
+
+// The packed counters in LDS are touched as 16-bit halves, 32-bit words and 16-byte
+// vectors; these typedefs keep type-based alias analysis from reordering them.
+typedef uint16_t __attribute__((may_alias)) u16_alias;
+typedef uint32_t __attribute__((may_alias)) u32_alias;
+
+template <typename Key>
+__device__ __forceinline__ uint32_t digit_of(Key key, int shift, Key flip, uint32_t mask)
+{
+    // `flip` is the sign bit for signed key types, 0 otherwise: the reference's
+    // `key + OFFSET` with OFFSET = -numeric_limits<T>::min() (RadixSortGPU.cpp:436-440,
+    // RadixSort.cl:51) is exactly an XOR of the sign bit.
+    return static_cast<uint32_t>((key ^ flip) >> shift) & mask;
+}
+
+// Workgroup -> tile.  Hardware deals consecutive workgroup ids round-robin over the 8
+// XCDs (observed, speed only).  With the remap every XCD walks its own contiguous range
+// of tiles, so the seam between the output runs of tiles t and t+1 (same digit,
+// adjacent addresses, usually inside one 128-B line) meets in ONE L2 and is merged
+// before it goes to HBM; the [digit][tile] table rows are written the same way.
+__device__ __forceinline__ uint32_t tile_of_block(uint32_t bid, uint32_t tiles_per_xcd, int remap)
+{
+    return remap ? (bid % kNumXcd) * tiles_per_xcd + bid / kNumXcd : bid;
+}
+
+// Inclusive prefix sum across the 64 lanes of a wave with DPP only (no LDS traffic):
+// Hillis-Steele inside each row of 16 lanes (row_shr 1,2,4,8), then the row totals are
+// carried with row_bcast:15 (rows 1,3) and row_bcast:31 (rows 2,3).
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
+{
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x111, 0xf, 0xf, false));
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x112, 0xf, 0xf, false));
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x114, 0xf, 0xf, false));
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x118, 0xf, 0xf, false));
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x142, 0xa, 0xf, false));
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x143, 0xc, 0xf, false));
+    return v;
+}
+
+// Exclusive prefix over the workgroup of one value per thread; `total` gets the sum.
+// `wtot` is LDS scratch of THREADS/64 words.  Contains two barriers.
+template <int THREADS>
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* wtot, uint32_t& total)
+{
+    constexpr int WAVES = THREADS / kWave;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = threadIdx.x / kWave;
+    const uint32_t incl = wave_inclusive_scan(v);
+    if (lane == kWave - 1) {
+        wtot[wave] = incl;
+    }
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+        const uint32_t t = wtot[w];
+        before += (static_cast<uint32_t>(w) < wave) ? t : 0u;
+        all += t;
+    }
+    total = all;
+    __syncthreads();   // wtot may be reused by the caller
+    return before + incl - v;
+}
+
+// ---------------------------------------------------------------------------
+// histogram: table[digit][tile] = number of keys of the tile with that digit
+// ---------------------------------------------------------------------------
+// HBM traffic: reads n*sizeof(Key) once, coalesced 16 B/lane; writes 64 B per tile.
+// Counting uses LDS atomics on 32 lane-private replicas of the 16 counters (row stride
+// 17 words): a wave whose keys all share one digit (Zeros, Range) still spreads over 32
+// banks instead of serialising on one address.
+template <typename Key, int THREADS, int KPT>
+__global__ __launch_bounds__(THREADS) void histogram_kernel(const Key* __restrict__ keys, uint32_t* __restrict__ table,
+                                                             uint64_t n, uint32_t ntiles, uint32_t tiles_per_xcd,
+                                                             int remap, int shift, Key flip, uint32_t mask)
+{
+    constexpr int TILE = THREADS * KPT;
+    constexpr int VEC = KeyVec<Key>::N;
+    constexpr int NV = KPT / VEC;
+    constexpr int REP = 32, RSTRIDE = kRadix + 1;
+    __shared__ uint32_t cnt[REP * RSTRIDE];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t tile = tile_of_block(blockIdx.x, tiles_per_xcd, remap);
+    if (tile >= ntiles) {
+        return;
+    }
+    for (uint32_t i = tid; i < REP * RSTRIDE; i += THREADS) {
+        cnt[i] = 0;
+    }
+    __syncthreads();
+
+    const uint64_t base = static_cast<uint64_t>(tile) * TILE;
+    const uint64_t left = n - base;
+    const uint32_t valid = left < static_cast<uint64_t>(TILE) ? static_cast<uint32_t>(left) : static_cast<uint32_t>(TILE);
+    uint32_t* mine = cnt + (tid & (REP - 1)) * RSTRIDE;
+
+    if (valid == TILE) {
+        KeyVec<Key> v[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            v[j] = *reinterpret_cast<const KeyVec<Key>*>(keys + base + static_cast<uint32_t>(j) * THREADS * VEC + tid * VEC);
+        }
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                atomicAdd(&mine[digit_of(v[j].k[e], shift, flip, mask)], 1u);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const uint32_t li = static_cast<uint32_t>(j) * THREADS * VEC + tid * VEC + e;
+                if (li < valid) {
+                    atomicAdd(&mine[digit_of(keys[base + li], shift, flip, mask)], 1u);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < kRadix) {
+        uint32_t s = 0;
+#pragma unroll
+        for (int r = 0; r < REP; ++r) {
+            s += cnt[r * RSTRIDE + tid];
+        }
+        table[static_cast<uint64_t>(tid) * ntiles + tile] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// scan of the flattened [digit][tile] table (ScanHistogram / PasteHistogram)
+// ---------------------------------------------------------------------------
+constexpr int kScanThreads = 256;
+constexpr int kScanPerThread = 16;
+constexpr int kScanBlock = kScanThreads * kScanPerThread;     // 4096 table entries per workgroup
+constexpr int kGlobsumThreads = 1024;
+constexpr int kGlobsumPerThread = 4;
+constexpr int kMaxScanBlocks = kGlobsumThreads * kGlobsumPerThread;   // 4096 block sums
+
+// scan #1: exclusive scan inside every block of 4096 entries, block total -> globsum[block]
+__global__ __launch_bounds__(kScanThreads) void scan_blocks_kernel(uint32_t* __restrict__ table, uint32_t* __restrict__ globsum,
+                                                                    uint64_t len)
+{
+    __shared__ uint32_t wtot[kScanThreads / kWave];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t first = static_cast<uint64_t>(blockIdx.x) * kScanBlock + static_cast<uint64_t>(tid) * kScanPerThread;
+    uint32_t v[kScanPerThread];
+    if (first + kScanPerThread <= len) {
+#pragma unroll
+        for (int q = 0; q < kScanPerThread / 4; ++q) {
+            const U32x4 x = *reinterpret_cast<const U32x4*>(table + first + q * 4);
+            v[q * 4 + 0] = x.v[0];
+            v[q * 4 + 1] = x.v[1];
+            v[q * 4 + 2] = x.v[2];
+            v[q * 4 + 3] = x.v[3];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < kScanPerThread; ++i) {
+            v[i] = (first + i < len) ? table[first + i] : 0u;
+        }
+    }
+    uint32_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < kScanPerThread; ++i) {
+        const uint32_t c = v[i];
+        v[i] = sum;
+        sum += c;
+    }
+    uint32_t total;
+    const uint32_t before = block_exclusive_scan<kScanThreads>(sum, wtot, total);
+    if (first + kScanPerThread <= len) {
+#pragma unroll
+        for (int q = 0; q < kScanPerThread / 4; ++q) {
+            U32x4 x;
+            x.v[0] = v[q * 4 + 0] + before;
+            x.v[1] = v[q * 4 + 1] + before;
+            x.v[2] = v[q * 4 + 2] + before;
+            x.v[3] = v[q * 4 + 3] + before;
+            *reinterpret_cast<U32x4*>(table + first + q * 4) = x;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < kScanPerThread; ++i) {
+            if (first + i < len) {
+                table[first + i] = v[i] + before;
+            }
+        }
+    }
+    if (tid == 0) {
+        globsum[blockIdx.x] = total;
+    }
+}
+
+// scan #2: exclusive scan of the block sums in place, grand total -> temp[0]
+__global__ __launch_bounds__(kGlobsumThreads) void scan_globsum_kernel(uint32_t* __restrict__ globsum, uint32_t* __restrict__ temp,
+                                                                        uint32_t nblocks)
+{
+    __shared__ uint32_t wtot[kGlobsumThreads / kWave];
+    const uint32_t tid = threadIdx.x;
+    uint32_t v[kGlobsumPerThread];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < kGlobsumPerThread; ++i) {
+        const uint32_t idx = tid * kGlobsumPerThread + i;
+        const uint32_t c = idx < nblocks ? globsum[idx] : 0u;
+        v[i] = sum;
+        sum += c;
+    }
+    uint32_t total;
+    const uint32_t before = block_exclusive_scan<kGlobsumThreads>(sum, wtot, total);
+#pragma unroll
+    for (int i = 0; i < kGlobsumPerThread; ++i) {
+        const uint32_t idx = tid * kGlobsumPerThread + i;
+        if (idx < nblocks) {
+            globsum[idx] = v[i] + before;
+        }
+    }
+    if (tid == 0) {
+        temp[0] = total;
+    }
+}
+
+// paste: every entry of block b += scanned globsum[b] -> table holds the global exclusive prefix
+__global__ __launch_bounds__(kScanThreads) void paste_kernel(uint32_t* __restrict__ table, const uint32_t* __restrict__ globsum,
+                                                              uint64_t len)
+{
+    const uint32_t add = globsum[blockIdx.x];
+    const uint64_t first = static_cast<uint64_t>(blockIdx.x) * kScanBlock + static_cast<uint64_t>(threadIdx.x) * kScanPerThread;
+    if (first + kScanPerThread <= len) {
+#pragma unroll
+        for (int q = 0; q < kScanPerThread / 4; ++q) {
+            U32x4 x = *reinterpret_cast<const U32x4*>(table + first + q * 4);
+            x.v[0] += add;
+            x.v[1] += add;
+            x.v[2] += add;
+            x.v[3] += add;
+            *reinterpret_cast<U32x4*>(table + first + q * 4) = x;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < kScanPerThread; ++i) {
+            if (first + i < len) {
+                table[first + i] += add;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// reorder: the stable scatter (the graded pass)
+// ---------------------------------------------------------------------------
+// LDS plan of one workgroup (dwords):
+//   xbuf  : first the striped->blocked transposition image (one row of KPT keys + 16 B
+//           pad per thread: ds_read_b128 of a row is bank-conflict-free), later the
+//           tile in locally sorted order (one pad element every 2^PADSH so that the
+//           stride-KPT writes of a single-digit tile do not pile on two banks)
+//   cnt   : 8 x THREADS packed counters, word [d&7][thread] holds digit d in its low
+//           (d<8) or high (d>=8) 16 bits
+//   wtot  : wave totals of the raking scan
+//   gbase : per digit, (global slot of the tile's first key of that digit) - (its local slot)
+template <typename Key, int THREADS, int KPT>
+struct ReorderLayout {
+    static constexpr int TILE = THREADS * KPT;
+    static constexpr int KD = sizeof(Key) / 4;
+    static constexpr int ROW_DW = KPT * KD + 4;
+    static constexpr int PADSH = (KD == 1) ? 5 : 4;
+    static constexpr int XELEMS = TILE + (TILE >> PADSH);
+    static constexpr int XBUF_DW = (THREADS * ROW_DW > XELEMS * KD) ? THREADS * ROW_DW : XELEMS * KD;
+    static constexpr int CNT_DW = 8 * THREADS;
+    static constexpr int WTOT_DW = 16;
+    static constexpr int GBASE_DW = kRadix;
+    static constexpr int TOTAL_DW = XBUF_DW + CNT_DW + WTOT_DW + GBASE_DW;
+    static constexpr size_t BYTES = static_cast<size_t>(TOTAL_DW) * 4;
+    static_assert(TILE <= 32768, "16-bit packed counters");
+    static_assert(KPT % (16 / sizeof(Key)) == 0 && THREADS % 64 == 0 && THREADS % 8 == 0, "geometry");
+};
+
+template <typename Key, int THREADS, int KPT, bool PAYLOAD>
+__global__ __launch_bounds__(THREADS) void reorder_kernel(const Key* __restrict__ in, Key* __restrict__ out,
+                                                           const uint32_t* __restrict__ pin, uint32_t* __restrict__ pout,
+                                                           const uint32_t* __restrict__ table, uint64_t n, uint32_t ntiles,
+                                                           uint32_t tiles_per_xcd, int remap, int shift, Key flip, uint32_t mask)
+{
+    using L = ReorderLayout<Key, THREADS, KPT>;
+    constexpr int TILE = L::TILE;
+    constexpr int VEC = KeyVec<Key>::N;
+    constexpr int NV = KPT / VEC;
+    constexpr int KD = L::KD;
+
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t* xbuf = smem;
+    uint32_t* cnt = smem + L::XBUF_DW;
+    uint32_t* wtot = cnt + L::CNT_DW;
+    uint32_t* gbase = wtot + L::WTOT_DW;
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t tile = tile_of_block(blockIdx.x, tiles_per_xcd, remap);
+    if (tile >= ntiles) {
+        return;
+    }
+    const uint64_t base = static_cast<uint64_t>(tile) * TILE;
+    const uint64_t left = n - base;
+    const uint32_t valid = left < static_cast<uint64_t>(TILE) ? static_cast<uint32_t>(left) : static_cast<uint32_t>(TILE);
+    const bool full = (valid == TILE);
+    // Slots past `valid` hold a key whose digit is 15 in every pass; being last in index
+    // order as well they land in local slots [valid, TILE) and are never stored.
+    const Key pad_key = static_cast<Key>(~flip);
+
+    // table[d][tile] for d = tid < 16, issued first so its latency hides under the key loads
+    uint32_t my_first_slot = 0;
+    if (tid < kRadix) {
+        my_first_slot = table[static_cast<uint64_t>(tid) * ntiles + tile];
+    }
+
+    // ---- 1. coalesced load (striped, 16 B per lane) -> LDS rows (blocked) ----------
+    {
+        KeyVec<Key> v[NV];
+        if (full) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                v[j] = *reinterpret_cast<const KeyVec<Key>*>(in + base + static_cast<uint32_t>(j) * THREADS * VEC + tid * VEC);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const uint32_t li = static_cast<uint32_t>(j) * THREADS * VEC + tid * VEC + e;
+                    v[j].k[e] = li < valid ? in[base + li] : pad_key;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const uint32_t li = static_cast<uint32_t>(j) * THREADS * VEC + tid * VEC;
+            const uint32_t owner = li / KPT;
+            const uint32_t within = li % KPT;
+            *reinterpret_cast<KeyVec<Key>*>(xbuf + owner * L::ROW_DW + within * KD) = v[j];
+        }
+    }
+    // payload of the thread's blocked keys straight from HBM (64 B contiguous per lane)
+    uint32_t pl[PAYLOAD ? KPT : 1];
+    if constexpr (PAYLOAD) {
+        if (full) {
+#pragma unroll
+            for (int q = 0; q < KPT / 4; ++q) {
+                const U32x4 x = *reinterpret_cast<const U32x4*>(pin + base + tid * KPT + q * 4);
+                pl[q * 4 + 0] = x.v[0];
+                pl[q * 4 + 1] = x.v[1];
+                pl[q * 4 + 2] = x.v[2];
+                pl[q * 4 + 3] = x.v[3];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                const uint32_t li = tid * KPT + i;
+                pl[i] = li < valid ? pin[base + li] : 0u;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- 2. each thread = one virtual processor: KPT consecutive keys, private counters
+    Key k[KPT];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const KeyVec<Key> v = *reinterpret_cast<const KeyVec<Key>*>(xbuf + tid * L::ROW_DW + j * VEC * KD);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            k[j * VEC + e] = v.k[e];
+        }
+    }
+    u16_alias* cnt16 = reinterpret_cast<u16_alias*>(cnt);
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+        cnt16[(l * THREADS + tid) * 2 + 0] = 0;
+        cnt16[(l * THREADS + tid) * 2 + 1] = 0;
+    }
+    uint32_t slot[KPT];      // first: rank among the thread's own equal-digit keys; later: tile-local slot
+    uint32_t cidx[KPT];      // index of the key's 16-bit counter
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        const uint32_t d = digit_of(k[i], shift, flip, mask);
+        cidx[i] = (((d & 7u) * THREADS + tid) << 1) + (d >> 3);
+        const uint32_t c = cnt16[cidx[i]];
+        slot[i] = c;
+        cnt16[cidx[i]] = static_cast<uint16_t>(c + 1);
+    }
+    __syncthreads();
+
+    // ---- 3. raking scan over the 8*THREADS packed words in [digit&7][thread] order ---
+    {
+        U32x4 a = *reinterpret_cast<const U32x4*>(cnt + tid * 8);
+        U32x4 b = *reinterpret_cast<const U32x4*>(cnt + tid * 8 + 4);
+        const uint32_t sum = a.v[0] + a.v[1] + a.v[2] + a.v[3] + b.v[0] + b.v[1] + b.v[2] + b.v[3];
+        uint32_t total;
+        uint32_t run = block_exclusive_scan<THREADS>(sum, wtot, total);
+        // low halves now prefix digits 0..7, high halves digits 8..15; the latter start
+        // after ALL keys with digit < 8, i.e. after total.low
+        run += total << 16;
+        uint32_t t;
+        t = a.v[0]; a.v[0] = run; run += t;
+        t = a.v[1]; a.v[1] = run; run += t;
+        t = a.v[2]; a.v[2] = run; run += t;
+        t = a.v[3]; a.v[3] = run; run += t;
+        t = b.v[0]; b.v[0] = run; run += t;
+        t = b.v[1]; b.v[1] = run; run += t;
+        t = b.v[2]; b.v[2] = run; run += t;
+        t = b.v[3]; b.v[3] = run;
+        *reinterpret_cast<U32x4*>(cnt + tid * 8) = a;
+        *reinterpret_cast<U32x4*>(cnt + tid * 8 + 4) = b;
+    }
+    __syncthreads();
+
+    // ---- 4. tile-local slot of every key; stage the tile in sorted order -------------
+    if (tid < kRadix) {
+        // thread 0's scanned counter of digit `tid` = local slot of the tile's first such key
+        const uint32_t local_first = cnt16[(((tid & 7u) * THREADS) << 1) + (tid >> 3)];
+        gbase[tid] = my_first_slot - local_first;
+    }
+    Key* xk = reinterpret_cast<Key*>(xbuf);
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        slot[i] += cnt16[cidx[i]];
+        xk[slot[i] + (slot[i] >> L::PADSH)] = k[i];
+    }
+    __syncthreads();
+
+    // ---- 5. leave as runs: consecutive lanes -> consecutive addresses inside a run ---
+    if constexpr (!PAYLOAD) {
+#pragma unroll
+        for (int r = 0; r < KPT; ++r) {
+            const uint32_t i = static_cast<uint32_t>(r) * THREADS + tid;
+            const Key key = xk[i + (i >> L::PADSH)];
+            const uint32_t g = gbase[digit_of(key, shift, flip, mask)] + i;
+            if (full || i < valid) {
+                out[g] = key;
+            }
+        }
+    } else {
+        Key okey[KPT];
+        uint32_t g[KPT];
+#pragma unroll
+        for (int r = 0; r < KPT; ++r) {
+            const uint32_t i = static_cast<uint32_t>(r) * THREADS + tid;
+            okey[r] = xk[i + (i >> L::PADSH)];
+            g[r] = gbase[digit_of(okey[r], shift, flip, mask)] + i;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            xbuf[slot[i] + (slot[i] >> 5)] = pl[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < KPT; ++r) {
+            const uint32_t i = static_cast<uint32_t>(r) * THREADS + tid;
+            const uint32_t p = xbuf[i + (i >> 5)];
+            if (full || i < valid) {
+                out[g[r]] = okey[r];
+                pout[g[r]] = p;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// small utility kernels
+// ---------------------------------------------------------------------------
+template <typename Key>
+__global__ void fill_kernel(Key* __restrict__ dst, uint64_t first, uint64_t count, Key value)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < count; i += stride) {
+        dst[first + i] = value;
+    }
+}
+
+// bucket start offsets of a finished (scanned + pasted) table: out[d] = table[d][0]
+__global__ void bucket_starts_kernel(const uint32_t* __restrict__ table, uint32_t ntiles, uint32_t* __restrict__ out)
+{
+    if (threadIdx.x < kRadix) {
+        out[threadIdx.x] = table[static_cast<uint64_t>(threadIdx.x) * ntiles];
+    }
+}
+
+}  // namespace rsx

@@ -1,0 +1,268 @@
+#include "CRadixSortTask.h"
+
+#include "CRadixSortCPU.h"
+#include "Common/CTimer.h"
+#include "Common/TypeInformation.h"
+#include "Dataset.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <ctime>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <numeric>
+#include <sstream>
+
+#include <sys/stat.h>
+
+namespace {
+
+constexpr double kHbmPeakGBs = 8000.0;   // MI355X HBM3E datasheet peak, the roofline denominator
+
+// std::sort referee (src/CRadixSortTask.cpp:32-43): copy-in + sort, both inside the timed region
+template <typename T>
+void SortDataSTL(std::span<const T> input, std::span<T> output)
+{
+    std::copy(input.begin(), input.end(), output.begin());
+    std::sort(output.begin(), output.end());
+}
+
+// CPU radix-sort referee (src/CRadixSortTask.cpp:50-58)
+template <typename T>
+void SortDataRadix(std::span<const T> input, std::span<T> output)
+{
+    std::copy(input.begin(), input.end(), output.begin());
+    RadixSortCPU<T>::sort(output);
+}
+
+}  // namespace
+
+void writePerformance(std::ostream& stream, const RuntimesGPU& g, const RuntimesCPU& c, std::size_t numberKeys,
+                      const std::string& datasetName, std::string_view datatype, std::size_t keyBytes, double avgTotalGPU_ms)
+{
+    // first ten columns: the reference's schema, same order (Performance/performance.csv:1)
+    stream << "NumElements,Datatype,Dataset,avgHistogram,avgScan,avgPaste,avgReorder,avgTotalGPU,avgTotalSTLCPU,avgTotalRDXCPU"
+           << ",MkeysPerSec,scatterGBs,scatterPctOfPeak,nGPU" << std::endl;
+    const double scatter_bytes = 2.0 * static_cast<double>(numberKeys) * static_cast<double>(keyBytes);
+    const double scatter_gbs = g.timeReorder.avg > 0 ? scatter_bytes / (g.timeReorder.avg * 1e-3) * 1e-9 : 0.0;
+    stream << numberKeys << "," << datatype << "," << datasetName << "," << g.timeHisto.avg << "," << g.timeScan.avg << ","
+           << g.timePaste.avg << "," << g.timeReorder.avg << "," << g.timeTotal.avg << "," << c.timeSTL.avg << "," << c.timeRadix.avg
+           << "," << (avgTotalGPU_ms > 0 ? static_cast<double>(numberKeys) / avgTotalGPU_ms * 1e-3 : 0.0) << "," << scatter_gbs << ","
+           << 100.0 * scatter_gbs / kHbmPeakGBs << ",1" << std::endl;
+}
+
+template <typename T>
+CRadixSortTask<T>::CRadixSortTask(const RadixSortOptions& options, std::shared_ptr<Dataset<T>> dataset)
+    : mNumberKeys(static_cast<std::uint32_t>(options.num_elements)),
+      mNumberKeysRounded(static_cast<std::uint32_t>(options.num_elements)),
+      mHostData(dataset, options.num_elements),
+      m_selectedDataset(dataset),
+      mOptions(options)
+{
+}
+
+template <typename T>
+std::uint32_t CRadixSortTask<T>::Resize(std::uint32_t nn)
+{
+    if (mOptions.verbose) std::cout << "Resizing to  " << nn << std::endl;
+    mNumberKeys = nn;
+    return mRadixSortGPU.Resize(nn);
+}
+
+template <typename T>
+bool CRadixSortTask<T>::InitResources(hipc::Device Device, hipc::Context Context)
+{
+    mNumberKeysRounded = Resize(mNumberKeys);
+    auto& hb = mHostData.mHostBuffers;
+    if (hb.m_hKeys.size() < mNumberKeysRounded) {
+        hb.m_hKeys.resize(mNumberKeysRounded, T{0});
+        const std::size_t old = hb.h_Permut.size();
+        hb.h_Permut.resize(mNumberKeysRounded);
+        std::iota(hb.h_Permut.begin() + static_cast<std::ptrdiff_t>(old), hb.h_Permut.end(), static_cast<std::uint32_t>(old));
+    }
+    hb.m_hResultFromGPU.resize(mNumberKeysRounded);
+
+    HostSpans<T> spans{
+        {hb.m_hKeys.data(), hb.m_hKeys.size()},
+        {hb.m_hHistograms.data(), hb.m_hHistograms.size()},
+        {hb.m_hGlobsum.data(), hb.m_hGlobsum.size()},
+        {hb.h_Permut.data(), hb.h_Permut.size()},
+        {hb.m_hResultFromGPU.data(), hb.m_hResultFromGPU.size()},
+    };
+    mRadixSortGPU.enablePermutation(mOptions.with_permutation);
+    mRadixSortGPU.setStepwise(mOptions.stepwise);
+    const auto status = mRadixSortGPU.initialize(Device, Context, mNumberKeys, spans);
+    if (status != OperationStatus::OK) {
+        std::cerr << "Failed to initialize Radix Sort on GPU: " << to_string(status) << " (" << static_cast<int>(status) << ")\n";
+    }
+    return status == OperationStatus::OK;
+}
+
+template <typename T>
+void CRadixSortTask<T>::ReleaseResources()
+{
+    mRadixSortGPU.release();
+}
+
+template <typename T>
+void CRadixSortTask<T>::ExecuteTask(hipc::Context, hipc::CommandQueue CommandQueue, const LocalWorkSize&)
+{
+    // uploadData -> calculate -> downloadData (src/CRadixSortTask.cpp:289-314); failures are
+    // recorded instead of asserted so that Release builds notice them too
+    if (mOptions.verbose) std::cout << "Sorting " << mNumberKeys << " keys..." << std::endl;
+    if (mOptions.with_permutation) {
+        auto& perm = mHostData.mHostBuffers.h_Permut;       // downloads overwrite it: restore the identity
+        std::iota(perm.begin(), perm.end(), 0U);
+    }
+    bool ok = mRadixSortGPU.uploadData(CommandQueue) == OperationStatus::OK;
+    ok = ok && mRadixSortGPU.calculate(CommandQueue) == OperationStatus::OK;
+    ok = ok && mRadixSortGPU.downloadData(CommandQueue) == OperationStatus::OK;
+    if (!ok) {
+        mExecutionFailed = true;
+        std::cerr << "GPU sort failed: " << rsx_last_error() << std::endl;
+    }
+    if (mOptions.verbose) std::cout << "Finished sorting." << std::endl;
+}
+
+template <typename T>
+void CRadixSortTask<T>::TestPerformance(hipc::CommandQueue CommandQueue, std::size_t numIterations)
+{
+    // wall clock around numIterations x (upload + sort + download), as the reference's
+    // avgTotalGPU (src/CRadixSortTask.cpp:357-378)
+    CTimer timer;
+    timer.Start();
+    for (std::size_t i = 0; i < numIterations; ++i) {
+        ExecuteTask({}, CommandQueue, {});
+    }
+    timer.Stop();
+    mAvgTotalGPUms = timer.GetElapsedMilliseconds() / static_cast<double>(numIterations);
+
+    const RuntimesGPU t = mRadixSortGPU.getRuntimes();
+    const std::string datasetName = m_selectedDataset->name();
+    const auto datatype = TypeNameString<T>::stdint_name;
+    if (mOptions.perf_to_stdout) {
+        std::cout << " kernel |    avg      |     min     |    max " << std::endl;
+        std::cout << " -----------------------------------------------" << std::endl;
+        auto row = [](const char* label, const Statistics& s) {
+            std::cout << label << std::setw(8) << s.avg << " | " << s.min << " | " << s.max << std::endl;
+        };
+        row("  histogram: ", t.timeHisto);
+        row("  scan:      ", t.timeScan);
+        row("  paste:     ", t.timePaste);
+        row("  reorder:   ", t.timeReorder);
+        std::cout << " -----------------------------------------------" << std::endl;
+        std::cout << "  total:     " << mAvgTotalGPUms << " ms, throughput: " << 1.0e-6 * static_cast<double>(mNumberKeysRounded) / mAvgTotalGPUms
+                  << " Gelem/s" << std::endl;
+        const double scatter_gbs = 2.0 * mNumberKeysRounded * sizeof(T) / (t.timeReorder.avg * 1e-3) * 1e-9;
+        std::cout << "  reorder pass: " << scatter_gbs << " GB/s algorithmic = " << 100.0 * scatter_gbs / kHbmPeakGBs
+                  << " % of the " << kHbmPeakGBs << " GB/s HBM3E peak" << std::endl;
+    }
+    if (mOptions.perf_to_csv) {
+        const std::time_t tt = std::chrono::system_clock::to_time_t(std::chrono::system_clock::now());
+        std::ostringstream name;
+        name << "radix_" << std::put_time(std::localtime(&tt), "%H-%M-%S") << ".csv";      // radix_HH-MM-SS.csv (:397-403)
+        struct stat sb;
+        if (stat(name.str().c_str(), &sb) == 0) {
+            std::cout << "File " << name.str() << " already exists, not overwriting!" << std::endl;
+        } else {
+            std::ofstream out(name.str(), std::ofstream::out | std::ofstream::app);
+            writePerformance(out, t, mRuntimesCPU, mNumberKeysRounded, datasetName, datatype, sizeof(T), mAvgTotalGPUms);
+        }
+    }
+    if (mOptions.perf_csv_to_stdout) {
+        writePerformance(std::cout, t, mRuntimesCPU, mNumberKeysRounded, datasetName, datatype, sizeof(T), mAvgTotalGPUms);
+    }
+}
+
+template <typename T>
+void CRadixSortTask<T>::ComputeGPU(hipc::Context Context, hipc::CommandQueue CommandQueue, const LocalWorkSize& lws)
+{
+    if (mNumberKeys != mNumberKeysRounded) {
+        mRadixSortGPU.padGPUData(CommandQueue, sizeof(T) * mNumberKeys);   // before upload, like the reference (:125-130)
+    }
+    ExecuteTask(Context, CommandQueue, lws);      // warm-up; its download is what ValidateResults checks
+
+    if (mOptions.perf_to_stdout) {
+        const auto& c = mRuntimesCPU;
+        std::cout << " radixsort cpu avg time: " << c.timeRadix.avg << " ms, throughput: "
+                  << 1.0e-6 * static_cast<double>(mNumberKeysRounded) / c.timeRadix.avg << " Gelem/s" << std::endl;
+        std::cout << " stl cpu avg time: " << c.timeSTL.avg << " ms, throughput: "
+                  << 1.0e-6 * static_cast<double>(mNumberKeysRounded) / c.timeSTL.avg << " Gelem/s" << std::endl;
+        std::cout << "Testing performance of GPU task RadixSort" << std::endl;
+    }
+    TestPerformance(CommandQueue, Parameters::_NUM_PERFORMANCE_ITERATIONS);
+}
+
+template <typename T>
+void CRadixSortTask<T>::ComputeCPU()
+{
+    if (mOptions.skip_cpu) return;
+    auto& hb = mHostData.mHostBuffers;
+    const std::span<const T> input(hb.m_hKeys.data(), mNumberKeysRounded);   // referees sort the ROUNDED array (:176-181)
+    // 5 iterations like the reference (src/Parameters.h:52) below 2^26 keys, 1 above (tens of seconds each)
+    const unsigned iters = mNumberKeysRounded >= (1U << 26) ? 1U : Parameters::_NUM_PERFORMANCE_ITERATIONS;
+    {
+        mHostData.m_resultSTLCPU.resize(mNumberKeysRounded);
+        std::span<T> output(mHostData.m_resultSTLCPU.data(), mNumberKeysRounded);
+        CTimer timer;
+        timer.Start();
+        for (unsigned j = 0; j < iters; ++j) SortDataSTL<T>(input, output);
+        timer.Stop();
+        mRuntimesCPU.timeSTL.avg = timer.GetElapsedMilliseconds() / iters;
+        mRuntimesCPU.timeSTL.n = iters;
+    }
+    {
+        mHostData.m_resultRadixSortCPU.resize(mNumberKeysRounded);
+        std::span<T> output(mHostData.m_resultRadixSortCPU.data(), mNumberKeysRounded);
+        CTimer timer;
+        timer.Start();
+        for (unsigned j = 0; j < iters; ++j) SortDataRadix<T>(input, output);
+        timer.Stop();
+        mRuntimesCPU.timeRadix.avg = timer.GetElapsedMilliseconds() / iters;
+        mRuntimesCPU.timeRadix.n = iters;
+    }
+}
+
+template <typename T>
+bool CRadixSortTask<T>::ValidateResults()
+{
+    // three-way check of the reference (src/CRadixSortTask.cpp:225-252): CPU radix vs std::sort
+    // and GPU vs std::sort over the first mNumberKeys elements — plus the direct GPU vs CPU-radix
+    // comparison the reference lacks, and (with --with-permutation) the argsort property.
+    bool success = !mExecutionFailed;
+    const auto& gpu = mHostData.mHostBuffers.m_hResultFromGPU;
+    const std::size_t bytes = sizeof(T) * mNumberKeys;
+    std::cout << "Data set: " << m_selectedDataset->name() << std::endl;
+    std::cout << "Data type: " << TypeNameString<T>::stdint_name << std::endl;
+    if (!mOptions.skip_cpu) {
+        const bool sortedCPU = std::memcmp(mHostData.m_resultRadixSortCPU.data(), mHostData.m_resultSTLCPU.data(), bytes) == 0;
+        std::cout << "Validation of CPU RadixSort has " << (sortedCPU ? "passed" : "FAILED") << std::endl;
+        const bool sortedGPU = std::memcmp(gpu.data(), mHostData.m_resultSTLCPU.data(), bytes) == 0;
+        std::cout << "Validation of GPU RadixSort has " << (sortedGPU ? "passed" : "FAILED") << std::endl;
+        const bool gpuVsRadix = std::memcmp(gpu.data(), mHostData.m_resultRadixSortCPU.data(), bytes) == 0;
+        std::cout << "GPU RadixSort vs CPU RadixSort (bit-exact): " << (gpuVsRadix ? "passed" : "FAILED") << std::endl;
+        success = success && sortedCPU && sortedGPU && gpuVsRadix;
+    } else {
+        const bool ascending = std::is_sorted(gpu.begin(), gpu.begin() + mNumberKeysRounded);
+        std::cout << "Validation of GPU RadixSort (ascending, CPU referees skipped) has " << (ascending ? "passed" : "FAILED") << std::endl;
+        success = success && ascending;
+    }
+    if (mOptions.with_permutation) {
+        const auto& perm = mHostData.mHostBuffers.h_Permut;
+        const auto& keys = mHostData.mHostBuffers.m_hKeys;
+        bool ok = true;
+        for (std::size_t i = 0; i < mNumberKeysRounded && ok; ++i) {
+            ok = perm[i] < mNumberKeysRounded && keys[perm[i]] == gpu[i] && (i == 0 || gpu[i - 1] != gpu[i] || perm[i - 1] < perm[i]);
+        }
+        std::cout << "Validation of GPU permutation (stable argsort) has " << (ok ? "passed" : "FAILED") << std::endl;
+        success = success && ok;
+    }
+    return success;
+}
+
+template class CRadixSortTask<std::int32_t>;
+template class CRadixSortTask<std::int64_t>;
+template class CRadixSortTask<std::uint32_t>;
+template class CRadixSortTask<std::uint64_t>;

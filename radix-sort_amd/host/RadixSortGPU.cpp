@@ -1,0 +1,233 @@
+#include "RadixSortGPU.h"
+
+#include "Common/CTimer.h"
+
+#include <limits>
+#include <type_traits>
+
+namespace {
+
+template <typename T>
+constexpr int key_is_signed = std::is_signed_v<T> ? 1 : 0;
+
+void accumulate(Statistics& dst, const rsx_phase_stat& src)
+{
+    // rsx_timings was read with reset=1: src holds only samples not yet folded in
+    if (src.n == 0) return;
+    dst.n += src.n;
+    dst.sum += src.sum_ms;
+    dst.avg = dst.sum / static_cast<double>(dst.n);
+    if (src.max_ms > dst.max) dst.max = src.max_ms;
+    if (src.min_ms < dst.min) dst.min = src.min_ms;
+}
+
+}  // namespace
+
+template <typename DataType>
+RadixSortGPU<DataType>::~RadixSortGPU()
+{
+    release();
+}
+
+template <typename DataType>
+std::uint32_t RadixSortGPU<DataType>::Resize(std::uint32_t nn) const noexcept
+{
+    // next multiple of _NUM_GROUPS * _NUM_ITEMS_PER_GROUP = 1024 (src/RadixSortGPU.cpp:288-297)
+    constexpr std::uint32_t granule = Parameters::_NUM_ITEMS;
+    const std::uint32_t rest = nn % granule;
+    return rest == 0 ? nn : nn + (granule - rest);
+}
+
+template <typename DataType>
+OperationStatus RadixSortGPU<DataType>::initialize(hipc::Device Device, hipc::Context Context, std::uint32_t nn,
+                                                   const HostSpans<DataType>& hostSpans)
+{
+    using S = OperationStatus;
+    if (!Context.valid() || Context.ordinal != Device.ordinal) return S::INITIALIZATION_FAILED;
+    if (nn == 0 || nn > Parameters::_ENGINE_MAX_ELEMS) return S::RESIZE_FAILED;
+    release();
+    mNumberKeysRounded = Resize(nn);
+    mHostSpans = hostSpans;                       // borrowed, caller keeps them alive (src/HostData.h:41-44)
+    if (!mHostSpans.m_hKeys.data() || !mHostSpans.m_hResultFromGPU.data()) return S::HOST_BUFFERS_FAILED;
+    if (mWithPermutation && !mHostSpans.h_Permut.data()) return S::HOST_BUFFERS_FAILED;
+
+    const int rc = rsx_create(&mEngine, Device.ordinal, static_cast<int>(sizeof(DataType)), key_is_signed<DataType>,
+                              mWithPermutation ? 1 : 0, mNumberKeysRounded);
+    if (rc != RSX_OK) {
+        mEngine = nullptr;
+        return static_cast<S>(rc);
+    }
+    rsx_resize(mEngine, mNumberKeysRounded);
+    rsx_set_option(mEngine, RSX_OPT_PROFILE, 1);   // RuntimesGPU is always filled, as in the reference
+    mRuntimesGPU = RuntimesGPU{};
+    mBoundStream = nullptr;
+    return S::OK;
+}
+
+template <typename DataType>
+OperationStatus RadixSortGPU<DataType>::release()
+{
+    if (!mEngine) return OperationStatus::OK;
+    const int rc = rsx_destroy(mEngine);
+    mEngine = nullptr;
+    return static_cast<OperationStatus>(rc);
+}
+
+template <typename DataType>
+bool RadixSortGPU<DataType>::bindQueue(hipc::CommandQueue CommandQueue)
+{
+    if (!mEngine) return false;
+    if (CommandQueue.stream && CommandQueue.stream != mBoundStream) {
+        if (rsx_set_stream(mEngine, CommandQueue.stream) != RSX_OK) return false;
+        mBoundStream = CommandQueue.stream;
+    }
+    return true;
+}
+
+template <typename DataType>
+void RadixSortGPU<DataType>::setLogStream(std::ostream* out) noexcept
+{
+    mOutStream = out;
+}
+
+template <typename DataType>
+void RadixSortGPU<DataType>::padGPUData(hipc::CommandQueue CommandQueue, std::size_t paddingOffset)
+{
+    // fills inputKeys from paddingOffset (bytes) with max()-1 (src/RadixSortGPU.cpp:270-285).
+    // Every caller of the reference pads BEFORE uploadData, which then overwrites the whole
+    // rounded length from the host span — so the effective padding is whatever the host
+    // buffer holds past nn.  Same here.
+    if (!bindQueue(CommandQueue)) return;
+    mLastStatus = rsx_fill_pad(mEngine, paddingOffset);
+}
+
+template <typename DataType>
+void RadixSortGPU<DataType>::CopyDataToDevice(hipc::CommandQueue)
+{
+    mLastStatus = rsx_upload(mEngine, mHostSpans.m_hKeys.data(), mWithPermutation ? mHostSpans.h_Permut.data() : nullptr,
+                             mNumberKeysRounded);
+}
+
+template <typename DataType>
+OperationStatus RadixSortGPU<DataType>::uploadData(hipc::CommandQueue CommandQueue)
+{
+    if (!bindQueue(CommandQueue)) return OperationStatus::DATA_UPLOAD_FAILED;
+    CopyDataToDevice(CommandQueue);
+    return mLastStatus == RSX_OK ? OperationStatus::OK : OperationStatus::DATA_UPLOAD_FAILED;
+}
+
+template <typename DataType>
+void RadixSortGPU<DataType>::CopyDataFromDevice(hipc::CommandQueue)
+{
+    // keys, permutation, digit table (first _RADIX*_NUM_ITEMS words) and block sums (first
+    // _NUM_HISTOSPLIT words) of the last pass (src/RadixSortGPU.cpp:390-429).  The two
+    // diagnostic read-backs follow THIS engine's geometry ([digit][tile], 4096-entry scan
+    // blocks), not the reference's [digit][group][item]; nothing consumes them.
+    mLastStatus = rsx_download(mEngine, mHostSpans.m_hResultFromGPU.data(), mWithPermutation ? mHostSpans.h_Permut.data() : nullptr,
+                               mHostSpans.m_hHistograms.data(), mHostSpans.m_hHistograms.data() ? Parameters::_RADIX * Parameters::_NUM_ITEMS : 0,
+                               mHostSpans.m_hGlobsum.data(), mHostSpans.m_hGlobsum.data() ? Parameters::_NUM_HISTOSPLIT : 0);
+}
+
+template <typename DataType>
+OperationStatus RadixSortGPU<DataType>::downloadData(hipc::CommandQueue CommandQueue)
+{
+    if (!bindQueue(CommandQueue)) return OperationStatus::DATA_DOWNLOAD_FAILED;
+    CopyDataFromDevice(CommandQueue);
+    return mLastStatus == RSX_OK ? OperationStatus::OK : OperationStatus::DATA_DOWNLOAD_FAILED;
+}
+
+// ---- stepwise launchers: enqueue, finish, host-time — the reference's accounting -------
+template <typename DataType>
+void RadixSortGPU<DataType>::Histogram(hipc::CommandQueue, int pass)
+{
+    CTimer timer;
+    timer.Start();
+    mLastStatus = rsx_histogram(mEngine, pass);
+    if (mLastStatus == RSX_OK) mLastStatus = rsx_sync(mEngine);
+    timer.Stop();
+    mRuntimesGPU.timeHisto.update(timer.GetElapsedMilliseconds());
+}
+
+template <typename DataType>
+void RadixSortGPU<DataType>::ScanHistogram(hipc::CommandQueue)
+{
+    {
+        CTimer timer;
+        timer.Start();
+        mLastStatus = rsx_scan(mEngine);            // scan #1 + scan #2
+        if (mLastStatus == RSX_OK) mLastStatus = rsx_sync(mEngine);
+        timer.Stop();
+        mRuntimesGPU.timeScan.update(timer.GetElapsedMilliseconds());
+    }
+    if (mLastStatus != RSX_OK) return;
+    {
+        CTimer timer;
+        timer.Start();
+        mLastStatus = rsx_paste(mEngine);
+        if (mLastStatus == RSX_OK) mLastStatus = rsx_sync(mEngine);
+        timer.Stop();
+        mRuntimesGPU.timePaste.update(timer.GetElapsedMilliseconds());
+    }
+}
+
+template <typename DataType>
+void RadixSortGPU<DataType>::Reorder(hipc::CommandQueue, int pass)
+{
+    CTimer timer;
+    timer.Start();
+    mLastStatus = rsx_reorder(mEngine, pass);       // includes the input/output buffer-name swap
+    if (mLastStatus == RSX_OK) mLastStatus = rsx_sync(mEngine);
+    timer.Stop();
+    mRuntimesGPU.timeReorder.update(timer.GetElapsedMilliseconds());
+}
+
+template <typename DataType>
+void RadixSortGPU<DataType>::foldEventTimings()
+{
+    rsx_runtimes t;
+    if (rsx_timings(mEngine, &t, /*reset=*/1) != RSX_OK) return;
+    accumulate(mRuntimesGPU.timeHisto, t.histogram);
+    accumulate(mRuntimesGPU.timeScan, t.scan);
+    accumulate(mRuntimesGPU.timePaste, t.paste);
+    accumulate(mRuntimesGPU.timeReorder, t.reorder);
+}
+
+template <typename DataType>
+OperationStatus RadixSortGPU<DataType>::calculate(hipc::CommandQueue CommandQueue)
+{
+    if (!bindQueue(CommandQueue)) return OperationStatus::CALCULATION_FAILED;
+    mLastStatus = RSX_OK;
+    if (mStepwise || mOutStream) {
+        rsx_set_option(mEngine, RSX_OPT_PROFILE, 0);
+        for (std::uint32_t pass = 0U; pass < Parameters::_NUM_PASSES && mLastStatus == RSX_OK; ++pass) {
+            if (mOutStream) *mOutStream << "Pass " << pass << ":\nBuilding histograms" << std::endl;
+            Histogram(CommandQueue, static_cast<int>(pass));
+            if (mOutStream) *mOutStream << "Scanning histograms" << std::endl;
+            if (mLastStatus == RSX_OK) ScanHistogram(CommandQueue);
+            if (mOutStream) *mOutStream << "Reordering " << std::endl;
+            if (mLastStatus == RSX_OK) Reorder(CommandQueue, static_cast<int>(pass));
+            if (mOutStream) *mOutStream << "-------------------" << std::endl;
+        }
+        rsx_set_option(mEngine, RSX_OPT_PROFILE, 1);
+    } else {
+        mLastStatus = rsx_sort(mEngine);
+        if (mLastStatus == RSX_OK) foldEventTimings();   // synchronises once, after the last pass
+    }
+    // timeTotal.avg = sum of the per-launch averages, n = histogram sample count
+    // (src/RadixSortGPU.cpp:337-343) — kept, although it is not a per-sort time.
+    mRuntimesGPU.timeTotal.avg = mRuntimesGPU.timeHisto.avg + mRuntimesGPU.timeScan.avg + mRuntimesGPU.timeReorder.avg + mRuntimesGPU.timePaste.avg;
+    mRuntimesGPU.timeTotal.n = mRuntimesGPU.timeHisto.n;
+    return mLastStatus == RSX_OK ? OperationStatus::OK : OperationStatus::CALCULATION_FAILED;
+}
+
+template <typename DataType>
+RuntimesGPU RadixSortGPU<DataType>::getRuntimes() const
+{
+    return mRuntimesGPU;
+}
+
+// the four key types of the reference (src/RadixSortGPU.cpp:598-601)
+template class RadixSortGPU<std::int32_t>;
+template class RadixSortGPU<std::int64_t>;
+template class RadixSortGPU<std::uint32_t>;
+template class RadixSortGPU<std::uint64_t>;

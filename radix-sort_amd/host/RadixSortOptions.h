@@ -1,0 +1,52 @@
+// RadixSortOptions.h — run-time flags of the harness, the reference's five
+// (/root/reference/src/RadixSortOptions.h:26-36) with identical spellings:
+//   --num-elements N   --perf-to-stdout   --perf-to-csv   --perf-csv-to-stdout   -v/--verbose
+// Differences: N is parsed as 64-bit (the reference's std::stoi cannot express 2^31 and
+// above) and a missing value after --num-elements is an error instead of reading past
+// the vector.  Extra, engine-specific switches are appended at the end.
+#pragma once
+
+#include "Parameters.h"
+
+#include <cstddef>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+struct RadixSortOptions {
+    std::size_t num_elements;
+    bool perf_to_stdout{false};
+    bool perf_to_csv{false};
+    bool perf_csv_to_stdout{false};
+    bool verbose{false};
+    // -- additions ---------------------------------------------------------------
+    bool with_permutation{false};   ///< --with-permutation: carry h_Permut through the sort (argsort)
+    bool stepwise{false};           ///< --stepwise: sync + host-time every launch like the reference
+    bool skip_cpu{false};           ///< --skip-cpu: no CPU referees (large sizes); validation uses sortedness
+
+    explicit RadixSortOptions(std::vector<std::string> args = {})
+        : num_elements(AlgorithmParameters<float>::_NUM_MAX_INPUT_ELEMS)   // default 2^25 (src/RadixSortOptions.h:18)
+    {
+        for (std::size_t i = 0; i < args.size(); ++i) {
+            const std::string& arg = args[i];
+            if (arg == "--num-elements") {
+                if (i + 1 >= args.size()) throw std::invalid_argument("--num-elements needs a value");
+                num_elements = static_cast<std::size_t>(std::stoull(args[++i]));
+            } else if (arg == "--perf-to-stdout") {
+                perf_to_stdout = true;
+            } else if (arg == "--perf-to-csv") {
+                perf_to_csv = true;
+            } else if (arg == "--perf-csv-to-stdout") {
+                perf_csv_to_stdout = true;
+            } else if (arg == "-v" || arg == "--verbose") {
+                verbose = true;
+            } else if (arg == "--with-permutation") {
+                with_permutation = true;
+            } else if (arg == "--stepwise") {
+                stepwise = true;
+            } else if (arg == "--skip-cpu") {
+                skip_cpu = true;
+            }
+        }
+    }
+};

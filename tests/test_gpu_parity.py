@@ -1,0 +1,312 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle.
+
+Bit-exact everywhere — integer work, no tolerance.  Inputs are the reference's dataset
+families (Dataset.h:84-137) at sizes the oracle finishes in seconds, the committed
+golden digests, edge sizes (empty, 1, non-multiples of the tile and of 1024), and the
+full BASELINE sizes through size-independent properties (sortedness + multiset
+checksums).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+DT = ["uint32", "int32", "uint64", "int64"]
+KINDS = ["Zeros", "Range", "InvertedRange", "SeededUniform", "Random"]   # tests.cpp:20-26
+
+
+@pytest.fixture(scope="module")
+def mod(rsx):
+    assert rsx.device_count() >= 1, "no HIP device: the product path has no CPU fallback"
+    return rsx
+
+
+def _sort(mod, keys, payload=None):
+    return mod.sort_host(keys, payload)
+
+
+# --------------------------------------------------------------------------- whole sort
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("kind", KINDS)
+def test_sort_matches_oracle_4x5_matrix(mod, oracle, dt, kind):
+    """The reference's own test matrix (tests/tests.cpp:18-27,83-87) at 2^16 keys."""
+    keys = oracle.dataset(kind, dt, 1 << 16)
+    got = _sort(mod, keys)
+    assert np.array_equal(got, oracle.radix_sort(keys))       # vs CRadixSortCPU restatement
+    assert np.array_equal(got, oracle.std_sort(keys))         # vs std::sort, the reference's ground truth
+
+
+def test_sort_matches_golden_digests(mod, oracle, golden):
+    for row in golden["datasets"]:
+        keys = oracle.dataset(row["kind"], row["dtype"], row["n"])
+        got = _sort(mod, keys)
+        assert oracle.digest(got) == row["sorted_digest"], row
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 1000, 1023, 1024, 1025, 4095, 4096, 4097, 8191, 12288, 100003])
+def test_sort_ragged_sizes(mod, oracle, dt, n):
+    rng = np.random.default_rng(n)
+    info = np.iinfo(dt)
+    keys = rng.integers(info.min, info.max, size=n, dtype=dt, endpoint=True)
+    assert np.array_equal(_sort(mod, keys), np.sort(keys))
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_sort_few_distinct_and_extremes(mod, oracle, dt):
+    rng = np.random.default_rng(5)
+    info = np.iinfo(dt)
+    pool = np.array([info.min, info.min + 1, -1 if info.min < 0 else 1, 0, 1, 15, 16, 255, 256, info.max - 1, info.max], dtype=dt)
+    keys = pool[rng.integers(0, pool.size, size=50000)]
+    got = _sort(mod, keys)
+    assert np.array_equal(got, np.sort(keys))
+    if keys.max() == info.max:      # inside the oracle's correct domain (full round count)
+        assert np.array_equal(got, oracle.radix_sort(keys))
+
+
+def test_sort_empty(mod):
+    with mod.Engine("uint32", 16) as e:
+        e.upload(np.empty(0, dtype=np.uint32))
+        e.sort()
+        assert e.download().size == 0
+
+
+def test_sort_2pow24_random(mod, oracle):
+    keys = oracle.dataset("Random", "uint32", 1 << 24)
+    got = _sort(mod, keys)
+    assert np.array_equal(got, np.sort(keys))
+
+
+# --------------------------------------------------------------------------- payload
+@pytest.mark.parametrize("dt", DT)
+def test_payload_is_stable_argsort(mod, oracle, dt):
+    """Payload semantics (unpinned in the reference, defined as stable argsort)."""
+    rng = np.random.default_rng(11)
+    info = np.iinfo(dt)
+    n = 70001
+    keys = rng.integers(0, 40, size=n, dtype=dt)      # heavy ties exercise stability
+    keys[::97] = info.max
+    if info.min < 0:
+        keys[1::97] = info.min
+    perm = np.arange(n, dtype=np.uint32)
+    ks, ps = _sort(mod, keys, perm)
+    want_k, want_p = oracle.radix_sort(keys, perm)
+    assert np.array_equal(ks, want_k)
+    assert np.array_equal(ps, want_p)
+    assert np.array_equal(ps, np.argsort(keys, kind="stable").astype(np.uint32))
+
+
+def test_payload_uint64_random_full_entropy(mod, oracle):
+    n = 1 << 18
+    keys = oracle.dataset("SeededUniform", "uint64", n)
+    perm = np.arange(n, dtype=np.uint32)
+    ks, ps = _sort(mod, keys, perm)
+    assert np.array_equal(ks, np.sort(keys))
+    assert np.array_equal(keys[ps], ks)
+    assert np.array_equal(ps, oracle.stable_argsort(keys, perm))
+
+
+# --------------------------------------------------------------------------- single steps
+def _digits(keys, pass_, signed_bits):
+    u = keys.view(np.uint32 if keys.dtype.itemsize == 4 else np.uint64).copy()
+    if signed_bits:
+        u ^= (np.uint64(1) << np.uint64(signed_bits - 1)).astype(u.dtype)
+    return ((u >> np.array(pass_ * 4, dtype=u.dtype)) & np.array(15, dtype=u.dtype)).astype(np.int64)
+
+
+@pytest.mark.parametrize("dt,n", [("uint32", 40000), ("int32", 4096 * 3), ("uint64", 10007), ("int64", 65536)])
+def test_histogram_scan_paste_reorder_steps(mod, oracle, dt, n):
+    """Each kernel against its host definition: table == per-tile digit counts
+    (RadixSort.cl:48-70 semantics at tile granularity), scan+paste == exclusive
+    prefix of the flattened [digit][tile] table (RadixSort.cl:125-197), reorder == one
+    stable counting pass (RadixSort.cl:96-118)."""
+    keys = oracle.dataset("SeededUniform", dt, n)
+    signed_bits = keys.dtype.itemsize * 8 if keys.dtype.kind == "i" else 0
+    with mod.Engine(dt, n) as e:
+        e.upload(keys)
+        g = e.geometry()
+        tile, ntiles = g.tile_keys, g.num_tiles
+        for pass_ in (0, 3, g.num_passes - 1):
+            d = _digits(keys, pass_, signed_bits)
+            want = np.zeros((16, ntiles), dtype=np.uint32)
+            for t in range(ntiles):
+                want[:, t] = np.bincount(d[t * tile:(t + 1) * tile], minlength=16)
+            e.histogram(pass_)
+            _, table = e.download(hist_cap=16 * ntiles)
+            assert np.array_equal(table.reshape(16, ntiles), want), pass_
+            e.scan()
+            e.paste()
+            _, table = e.download(hist_cap=16 * ntiles)
+            flat = want.reshape(-1).astype(np.uint64)
+            excl = np.concatenate([[0], np.cumsum(flat)[:-1]]).astype(np.uint32)
+            assert np.array_equal(table, excl), pass_
+            e.reorder(pass_)
+            got = e.download()
+            assert np.array_equal(got, keys[np.argsort(d, kind="stable")]), pass_
+            e.upload(keys)      # back to the original order for the next pass under test
+
+
+def test_globsum_is_exclusive_scan_of_block_sums(mod, oracle):
+    n = 1 << 20
+    keys = oracle.dataset("Random", "uint32", n)
+    with mod.Engine("uint32", n) as e:
+        e.upload(keys)
+        e.histogram(0)
+        _, counts = e.download(hist_cap=16 * e.geometry().num_tiles)
+        e.scan()
+        g = e.geometry()
+        _, gs = e.download(globsum_cap=int(g.num_scan_blocks))
+        pad = (-counts.size) % g.scan_block
+        sums = np.concatenate([counts, np.zeros(pad, dtype=np.uint32)]).reshape(-1, g.scan_block).sum(axis=1)
+        assert np.array_equal(gs, np.concatenate([[0], np.cumsum(sums)[:-1]]).astype(np.uint32))
+
+
+def test_xcd_remap_does_not_change_results(mod, oracle):
+    keys = oracle.dataset("Random", "uint32", 300001)
+    outs = []
+    for remap in (0, 1):
+        with mod.Engine("uint32", keys.size) as e:
+            e.set_option(mod.OPT_XCD_REMAP, remap)
+            e.upload(keys)
+            e.sort()
+            outs.append(e.download())
+    assert np.array_equal(outs[0], outs[1])
+    assert np.array_equal(outs[0], np.sort(keys))
+
+
+# --------------------------------------------------------------------------- reference semantics
+def test_fill_pad_value_and_rounded_length(mod, oracle):
+    """padGPUData writes max()-1 from a byte offset (RadixSortGPU.cpp:270-285); the sort
+    covers exactly the uploaded (rounded) length."""
+    for dt in DT:
+        info = np.iinfo(dt)
+        n, rounded = 1000, 1024
+        host = np.zeros(rounded, dtype=dt)
+        host[:n] = oracle.dataset("Random", dt, n)
+        with mod.Engine(dt, rounded) as e:
+            e.upload(host)
+            e.fill_pad(n * host.dtype.itemsize)
+            padded = e.download()
+            assert np.array_equal(padded[:n], host[:n])
+            assert np.all(padded[n:] == info.max - 1)
+            e.sort()
+            assert np.array_equal(e.download(), np.sort(padded))
+            # the reference's real call order: pad first, upload afterwards overwrites the pad
+            e.fill_pad(n * host.dtype.itemsize)
+            e.upload(host)
+            e.sort()
+            assert np.array_equal(e.download(), np.sort(host))
+
+
+def test_result_lands_in_input_buffer_after_even_passes(mod, oracle):
+    """8 / 16 passes end in the buffer named inputKeys (RadixSortGPU.cpp:263-266,394-400)."""
+    keys = oracle.dataset("Random", "uint64", 5000)
+    with mod.Engine("uint64", 5000) as e:
+        e.upload(keys)
+        before, _ = e.result_device()
+        e.sort()
+        after, _ = e.result_device()
+        assert before == after
+        assert np.array_equal(e.download(), np.sort(keys))
+
+
+def test_timings_profile_mode(mod, oracle):
+    keys = oracle.dataset("Random", "uint32", 1 << 20)
+    with mod.Engine("uint32", keys.size) as e:
+        e.set_option(mod.OPT_PROFILE, 1)
+        e.upload(keys)
+        e.sort()
+        t = e.timings()
+        assert t.histogram.n == 8 and t.reorder.n == 8 and t.paste.n == 8
+        assert t.scan.n == 16                      # two scan launches per pass (RadixSortGPU.cpp:108,147)
+        assert t.total.n == 1 and t.total.sum_ms >= t.reorder.sum_ms > 0
+        assert t.reorder.min_ms <= t.reorder.avg_ms <= t.reorder.max_ms
+        assert np.array_equal(e.download(), np.sort(keys))
+
+
+def test_errors_map_to_operation_status(mod):
+    with pytest.raises(mod.RadixSortError) as ei:
+        mod.Engine("uint32", 0)
+    assert ei.value.status == 7                     # RESIZE_FAILED
+    with mod.Engine("uint32", 100) as e:
+        with pytest.raises(mod.RadixSortError) as ei:
+            e.upload(np.zeros(101, dtype=np.uint32))
+        assert ei.value.status == 3                 # DATA_UPLOAD_FAILED
+        with pytest.raises(mod.RadixSortError) as ei:
+            e.histogram(8)
+        assert ei.value.status == 4                 # CALCULATION_FAILED
+    with mod.Engine("uint32", 100, payload=True) as e:
+        with pytest.raises(mod.RadixSortError) as ei:
+            e.upload(np.zeros(10, dtype=np.uint32), None)
+        assert ei.value.status == 1                 # HOST_BUFFERS_FAILED
+
+
+# --------------------------------------------------------------------------- device-resident API
+def test_sort_from_torch_tensor_leaves_input_untouched(mod, oracle):
+    import torch
+    keys = oracle.dataset("Random", "int32", 123457)
+    t = torch.from_numpy(keys).cuda()
+    with mod.Engine("int32", keys.size) as e:
+        e.set_stream(torch.cuda.current_stream().cuda_stream)
+        e.sort_from(t.data_ptr(), keys.size)
+        out = torch.empty_like(t)
+        e.copy_result(out.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(t.cpu().numpy(), keys)
+        assert np.array_equal(out.cpu().numpy(), np.sort(keys))
+        assert np.array_equal(e.download(), np.sort(keys))
+
+
+@pytest.mark.parametrize("bits", [1, 2, 3, 4])
+def test_partition_by_top_bits(mod, oracle, bits):
+    import torch
+    n = 200003
+    keys = oracle.dataset("SeededUniform", "uint32", n)
+    perm = np.arange(n, dtype=np.uint32)
+    tk, tp = torch.from_numpy(keys).cuda(), torch.from_numpy(perm.view(np.int32)).cuda()
+    ok, op = torch.empty_like(tk), torch.empty_like(tp)
+    with mod.Engine("uint32", n, payload=True) as e:
+        e.set_stream(torch.cuda.current_stream().cuda_stream)
+        offs = e.partition(tk.data_ptr(), n, 32 - bits, bits, ok.data_ptr(), tp.data_ptr(), op.data_ptr())
+        torch.cuda.synchronize()
+    d = (keys >> np.uint32(32 - bits)).astype(np.int64)
+    order = np.argsort(d, kind="stable")
+    assert np.array_equal(ok.cpu().numpy(), keys[order])
+    assert np.array_equal(op.cpu().numpy().view(np.uint32), perm[order])
+    counts = np.bincount(d, minlength=1 << bits)
+    assert offs == [0] + [int(v) for v in np.cumsum(counts)]
+
+
+# --------------------------------------------------------------------------- BASELINE sizes
+def _checksums(a):
+    u = a.view(np.uint32 if a.dtype.itemsize == 4 else np.uint64).astype(np.uint64, copy=False)
+    return int(np.bitwise_xor.reduce(u)), int(u.sum(dtype=np.uint64)), int((u * u).sum(dtype=np.uint64))
+
+
+@pytest.mark.parametrize("kind", ["Random", "Zeros", "InvertedRange", "SeededUniform"])
+def test_full_size_2pow28_uint32_properties(mod, oracle, kind):
+    """BASELINE configs 2 and 5 at full size: output is ascending and is a permutation
+    of the input (xor / sum / sum-of-squares checksums mod 2^64)."""
+    n = 1 << 28
+    keys = oracle.dataset(kind, "uint32", n)
+    got = _sort(mod, keys)
+    assert got.size == n
+    assert bool(np.all(got[:-1] <= got[1:]))
+    assert _checksums(got) == _checksums(keys)
+    if kind == "InvertedRange":
+        assert np.array_equal(got, keys[::-1])
+    if kind == "Zeros":
+        assert not got.any()
+
+
+def test_full_size_2pow28_uint64_with_payload(mod, oracle):
+    """BASELINE config 3: 2^28 uint64 keys + uint32 payload (h_Permut = iota)."""
+    n = 1 << 28
+    keys = oracle.dataset("SeededUniform", "uint64", n)
+    perm = np.arange(n, dtype=np.uint32)
+    ks, ps = _sort(mod, keys, perm)
+    assert bool(np.all(ks[:-1] <= ks[1:]))
+    assert _checksums(ks) == _checksums(keys)
+    assert np.array_equal(keys[ps], ks)               # payload followed its key
+    ties = np.flatnonzero(ks[:-1] == ks[1:])
+    assert bool(np.all(ps[ties] < ps[ties + 1]))      # stability on equal keys
