@@ -1,0 +1,52 @@
+"""GPU runs of the C++ host mirror: the reference's integration test shape
+(tests/tests.cpp: 4 key types x 5 datasets through CRadixSortTask) and the basic_sort
+example, as compiled binaries over the C ABI."""
+import os
+import re
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "radix-sort_amd", "host", "bin")
+
+
+def _run(args, timeout=900):
+    return subprocess.run(args, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("n", [1000, 1 << 16, (1 << 20) + 5])
+def test_main_test_matrix(n):
+    """All 20 (type, dataset) tasks validate: CPU radix == std::sort, GPU == std::sort,
+    GPU == CPU radix (src/CRadixSortTask.cpp:225-252 plus the direct comparison)."""
+    proc = _run([os.path.join(BIN, "rsx_tests"), "--num-elements", str(n)])
+    assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-2000:]
+    assert proc.stdout.count("GOLD TEST PASSED!") == 20
+    assert "FAILED" not in proc.stdout and "INVALID RESULTS" not in proc.stdout
+    assert "20/20 task runs validated" in proc.stdout
+
+
+def test_main_test_with_permutation_and_stepwise():
+    proc = _run([os.path.join(BIN, "rsx_tests"), "--num-elements", "50000", "--with-permutation", "--stepwise"])
+    assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-2000:]
+    assert proc.stdout.count("Validation of GPU permutation (stable argsort) has passed") == 20
+
+
+def test_perf_csv_schema_on_stdout():
+    proc = _run([os.path.join(BIN, "rsx_tests"), "--num-elements", "65536", "--perf-csv-to-stdout", "--perf-to-stdout"])
+    assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-2000:]
+    header = "NumElements,Datatype,Dataset,avgHistogram,avgScan,avgPaste,avgReorder,avgTotalGPU,avgTotalSTLCPU,avgTotalRDXCPU"
+    assert proc.stdout.count(header) == 20
+    rows = re.findall(r"^65536,(u?int(?:32|64)_t),([A-Za-z ]+),", proc.stdout, flags=re.M)
+    assert len(rows) == 20 and {r[0] for r in rows} == {"uint32_t", "int32_t", "uint64_t", "int64_t"}
+    assert "reorder pass:" in proc.stdout and "% of the 8000 GB/s HBM3E peak" in proc.stdout
+
+
+def test_basic_sort_example():
+    proc = _run([os.path.join(BIN, "basic_sort")])
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-2000:]
+    assert "Result: PASSED" in proc.stdout
+    proc = _run([os.path.join(BIN, "basic_sort"), "1000003"])
+    assert proc.returncode == 0 and "Result: PASSED" in proc.stdout

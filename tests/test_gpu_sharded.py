@@ -1,0 +1,107 @@
+"""The sharded-sort driver with the REAL HIP engine, two ranks emulated as two threads on
+one GPU (the test box has a single MI355X; RCCL refuses two ranks on one device).  The
+collectives are a loopback object with torch.distributed's call signatures; everything
+else — rsx_partition, split planning, rsx_sort_from on the received keys — is the product
+path.  The 8-GPU RCCL run itself is the driver's scaling bench."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+class _Loopback:
+    def __init__(self, world):
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+
+    def view(self, rank):
+        return _RankDist(self, rank)
+
+
+class _RankDist:
+    def __init__(self, hub, rank):
+        self.hub, self.rank = hub, rank
+
+    def all_gather_into_tensor(self, out, t):
+        import torch
+        torch.cuda.synchronize()
+        self.hub.slots[self.rank] = t
+        self.hub.barrier.wait()
+        out.copy_(torch.cat([self.hub.slots[i] for i in range(self.hub.world)]))
+        torch.cuda.synchronize()
+        self.hub.barrier.wait()
+
+    def all_to_all_single(self, out, inp, out_splits, in_splits):
+        import torch
+        torch.cuda.synchronize()
+        self.hub.slots[self.rank] = (inp, in_splits)
+        self.hub.barrier.wait()
+        pos = 0
+        for src in range(self.hub.world):
+            s_inp, s_splits = self.hub.slots[src]
+            off, cnt = sum(s_splits[:self.rank]), s_splits[self.rank]
+            assert cnt == out_splits[src]
+            out[pos:pos + cnt].copy_(s_inp[off:off + cnt])
+            pos += cnt
+        torch.cuda.synchronize()
+        self.hub.barrier.wait()
+
+
+@pytest.mark.parametrize("dtype,kind,with_payload", [("uint32", "SeededUniform", False), ("int64", "SeededUniform", True), ("uint32", "Zeros", True)])
+def test_two_ranks_on_one_gpu(rsx, oracle, dtype, kind, with_payload):
+    import torch
+    from radix_sort_amd.distributed import ShardedSorter
+    world, n = 2, 100003
+    full = oracle.dataset(kind, dtype, n * world, seed=31)
+    hub = _Loopback(world)
+    results, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            shard = full[rank * n:(rank + 1) * n].copy()
+            signed = {"uint32": np.int32, "uint64": np.int64}.get(np.dtype(dtype).name)
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                keys = torch.from_numpy(shard.view(signed) if signed else shard).cuda()
+                staging = torch.empty_like(keys)
+                recv = torch.empty(n * world, dtype=keys.dtype, device="cuda")
+                pay = spay = rpay = None
+                if with_payload:
+                    pay = torch.arange(rank * n, (rank + 1) * n, dtype=torch.int32, device="cuda")
+                    spay = torch.empty_like(pay)
+                    rpay = torch.empty(n * world, dtype=torch.int32, device="cuda")
+                with rsx.Engine(dtype, n * world, payload=with_payload) as eng:
+                    eng.set_stream(stream.cuda_stream)
+                    sorter = ShardedSorter(eng, rank, world, np.dtype(dtype).itemsize * 8, hub.view(rank))
+                    n_local = sorter.sort(keys, staging, recv, pay, spay, rpay)
+                    out = eng.download(want_perm=True) if with_payload else (eng.download(), None)
+                    results[rank] = (n_local, out[0], out[1])
+        except Exception as exc:   # noqa: BLE001 - surface in the main thread
+            errors.append(exc)
+            hub.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    got = np.concatenate([r[1] for r in results])
+    assert sum(r[0] for r in results) == full.size
+    assert np.array_equal(got, np.sort(full, kind="stable"))
+    if with_payload:
+        assert np.array_equal(np.concatenate([r[2] for r in results]), np.argsort(full, kind="stable").astype(np.uint32))
+
+
+def test_world_size_one_is_plain_sort(rsx, oracle):
+    import torch
+    from radix_sort_amd.distributed import ShardedSorter
+    keys_np = oracle.dataset("Random", "uint32", 50000)
+    keys = torch.from_numpy(keys_np.view(np.int32)).cuda()
+    with rsx.Engine("uint32", keys_np.size) as eng:
+        eng.set_stream(torch.cuda.current_stream().cuda_stream)
+        assert ShardedSorter(eng, 0, 1, 32).sort(keys, None, None) == keys_np.size
+        assert np.array_equal(eng.download(), np.sort(keys_np))

@@ -1,0 +1,69 @@
+"""CPU tests of the host mirror of the reference interface (radix-sort_amd/host):
+the C++ self-test binary, and the product's Dataset generators against the golden
+vectors produced by the reference's own Dataset.h."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "radix-sort_amd", "host")
+KINDS = {"Zeros": 0, "Range": 1, "InvertedRange": 2, "Random": 3, "RandomDistributed": 4}
+DTYPES = {"uint32": 0, "int32": 1, "uint64": 2, "int64": 3}
+
+
+@pytest.fixture(scope="module")
+def hostlib():
+    lib = C.CDLL(os.path.join(HOST, "libradixsort_host.so"))
+    lib.rsxh_dataset_fill.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64]
+    lib.rsxh_dataset_fill.restype = C.c_int
+    lib.rsxh_resize.argtypes = [C.c_uint32]
+    lib.rsxh_resize.restype = C.c_uint32
+    lib.rsxh_default_uniform_seed.restype = C.c_uint64
+    return lib
+
+
+def _fill(lib, kind, dt, n, seed=0):
+    out = np.empty(n, dtype=dt)
+    assert lib.rsxh_dataset_fill(KINDS[kind], DTYPES[dt], out.ctypes.data, n, seed) == 0
+    return out
+
+
+def test_host_selftest_binary():
+    exe = os.path.join(HOST, "bin", "host_selftest")
+    proc = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 0, proc.stdout + proc.stderr
+    assert "checks passed" in proc.stdout
+
+
+def test_product_datasets_match_reference_goldens(hostlib, oracle, golden):
+    # same inputs as the reference's generators (golden digests come from its Dataset.h)
+    for row in golden["datasets"]:
+        got = _fill(hostlib, row["kind"], row["dtype"], row["n"])
+        assert oracle.digest(got) == row["input_digest"], row
+    for row in golden["small_vectors"]:
+        assert [int(v) for v in _fill(hostlib, row["kind"], row["dtype"], row["n"])] == row["input"]
+
+
+def test_product_uniform_dataset_matches_oracle_standin(hostlib, oracle):
+    seed = int(hostlib.rsxh_default_uniform_seed())
+    for dt in DTYPES:
+        a = _fill(hostlib, "RandomDistributed", dt, 4099, seed)
+        assert np.array_equal(a, oracle.dataset("SeededUniform", dt, 4099, seed))
+
+
+def test_resize_rounds_to_1024(hostlib):
+    # RadixSortGPU::Resize (reference src/RadixSortGPU.cpp:288-297)
+    for nn, want in [(0, 0), (1, 1024), (1000, 1024), (1024, 1024), (1025, 2048), (1 << 25, 1 << 25), ((1 << 28) + 1, (1 << 28) + 1024)]:
+        assert hostlib.rsxh_resize(nn) == want
+
+
+def test_harness_refuses_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    exe = os.path.join(HOST, "bin", "rsx_tests")
+    proc = subprocess.run([exe, "--num-elements", "2048"], capture_output=True, text=True, timeout=120)
+    assert proc.returncode == 2 and "no CPU fallback" in proc.stderr
