@@ -34,7 +34,7 @@ public:
         }
     }
 
-private:
+    /// Counting rounds the sort runs for a given raw maximum (src/CRadixSortCPU.h:62,67).
     template <typename ElemType>
     static std::uint64_t roundsFor(ElemType maxElem)
     {
@@ -44,6 +44,33 @@ private:
         return static_cast<std::uint64_t>(std::ceil(std::log(mag) / std::log(NUM_BINS)));
     }
 
+    /// True when the round count covers every significant bit of the biased keys, i.e. the
+    /// input lies in the domain where this referee is a correct sort.  Outside it (raw
+    /// maximum an exact power of the base, or small while negative keys are present — e.g.
+    /// a signed Range padded with zeros) the reference's algorithm stops early.
+    template <typename ElemType>
+    static bool coversAllDigits(std::span<const ElemType> arr)
+    {
+        using U = std::make_unsigned_t<ElemType>;
+        if (arr.empty()) return true;
+        constexpr U bias = static_cast<U>(std::numeric_limits<ElemType>::min());
+        U top = 0;
+        ElemType rawMax = arr.front();
+        for (const ElemType v : arr) {
+            top = std::max<U>(top, static_cast<U>(static_cast<U>(v) - bias));
+            rawMax = std::max(rawMax, v);
+        }
+        unsigned bits = 0;
+        while (top) {
+            ++bits;
+            top >>= 1;
+        }
+        unsigned perRound = 0;
+        for (std::uint32_t b = NUM_BINS; b > 1; b >>= 1) ++perRound;   // log2(NUM_BINS)
+        return roundsFor(rawMax) * perRound >= bits;
+    }
+
+private:
     template <typename ElemType>
     static void countSort(std::span<ElemType>& arr, std::vector<ElemType>& scratch, std::uint64_t weight)
     {

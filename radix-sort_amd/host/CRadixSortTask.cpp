@@ -237,13 +237,27 @@ bool CRadixSortTask<T>::ValidateResults()
     std::cout << "Data set: " << m_selectedDataset->name() << std::endl;
     std::cout << "Data type: " << TypeNameString<T>::stdint_name << std::endl;
     if (!mOptions.skip_cpu) {
+        // The CPU radix referee derives its round count from the raw maximum; on inputs where
+        // that stops short (e.g. signed Range whose rounded tail is zero-padded) it is not a
+        // sort at all, in the reference too.  It is judged only inside its correct domain;
+        // std::sort is the ground truth everywhere (SURVEY §4 "referee hierarchy").
+        const std::span<const T> sortedInput(mHostData.mHostBuffers.m_hKeys.data(), mNumberKeysRounded);
+        const bool inDomain = RadixSortCPU<T>::coversAllDigits(sortedInput);
         const bool sortedCPU = std::memcmp(mHostData.m_resultRadixSortCPU.data(), mHostData.m_resultSTLCPU.data(), bytes) == 0;
-        std::cout << "Validation of CPU RadixSort has " << (sortedCPU ? "passed" : "FAILED") << std::endl;
+        if (inDomain) {
+            std::cout << "Validation of CPU RadixSort has " << (sortedCPU ? "passed" : "FAILED") << std::endl;
+        } else {
+            std::cout << "Validation of CPU RadixSort skipped: input outside the referee's domain (round count from raw maximum); "
+                      << "it " << (sortedCPU ? "still matches" : "differs from") << " std::sort" << std::endl;
+        }
         const bool sortedGPU = std::memcmp(gpu.data(), mHostData.m_resultSTLCPU.data(), bytes) == 0;
         std::cout << "Validation of GPU RadixSort has " << (sortedGPU ? "passed" : "FAILED") << std::endl;
-        const bool gpuVsRadix = std::memcmp(gpu.data(), mHostData.m_resultRadixSortCPU.data(), bytes) == 0;
-        std::cout << "GPU RadixSort vs CPU RadixSort (bit-exact): " << (gpuVsRadix ? "passed" : "FAILED") << std::endl;
-        success = success && sortedCPU && sortedGPU && gpuVsRadix;
+        success = success && sortedGPU && (sortedCPU || !inDomain);
+        if (inDomain) {
+            const bool gpuVsRadix = std::memcmp(gpu.data(), mHostData.m_resultRadixSortCPU.data(), bytes) == 0;
+            std::cout << "GPU RadixSort vs CPU RadixSort (bit-exact): " << (gpuVsRadix ? "passed" : "FAILED") << std::endl;
+            success = success && gpuVsRadix;
+        }
     } else {
         const bool ascending = std::is_sorted(gpu.begin(), gpu.begin() + mNumberKeysRounded);
         std::cout << "Validation of GPU RadixSort (ascending, CPU referees skipped) has " << (ascending ? "passed" : "FAILED") << std::endl;

@@ -106,6 +106,16 @@ int main()
         CHECK((w == std::vector<std::int32_t>{0, 5, 100, -100, -3}));
     }
 
+    // domain test of the referee: full-range data is inside, zero-padded signed Range is not
+    {
+        std::vector<std::int32_t> in_dom{std::numeric_limits<std::int32_t>::max(), -5, 7};
+        std::vector<std::int32_t> out_dom{std::numeric_limits<std::int32_t>::min(), std::numeric_limits<std::int32_t>::min() + 1, 0};
+        std::vector<std::uint32_t> pow_of_base{8, 1, 0, 7};
+        CHECK(RadixSortCPU<std::int32_t>::coversAllDigits(std::span<const std::int32_t>(in_dom)));
+        CHECK(!RadixSortCPU<std::int32_t>::coversAllDigits(std::span<const std::int32_t>(out_dom)));
+        CHECK(!RadixSortCPU<std::uint32_t>::coversAllDigits(std::span<const std::uint32_t>(pow_of_base)));
+    }
+
     // OperationStatus values (src/OperationStatus.h:4-17) == rsx_status
     CHECK(static_cast<int>(OperationStatus::OK) == RSX_OK && static_cast<int>(OperationStatus::RESIZE_FAILED) == RSX_RESIZE_FAILED);
     CHECK(static_cast<int>(OperationStatus::LOADING_SOURCE_FAILED) == 11 && static_cast<int>(OperationStatus::DATA_DOWNLOAD_FAILED) == RSX_DATA_DOWNLOAD_FAILED);
