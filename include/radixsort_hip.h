@@ -53,10 +53,13 @@ typedef struct rsx_engine rsx_engine;   /* opaque */
 
 /* Options for rsx_set_option. */
 typedef enum rsx_option {
-    RSX_OPT_PROFILE = 0,      /* 1: bracket every kernel launch with HIP events (RuntimesGPU) */
+    RSX_OPT_PROFILE = 0,      /* HIP events around launches -> RuntimesGPU: 0 off, 1 every launch, 2 reorder only */
     RSX_OPT_XCD_REMAP = 1,    /* 1 (default): consecutive tiles run on one XCD (L2 merges run seams) */
     RSX_OPT_FIRST_PASS = 2,   /* first pass of rsx_sort (default 0) */
-    RSX_OPT_LAST_PASS = 3     /* one past the last pass of rsx_sort (default bits/4) */
+    RSX_OPT_LAST_PASS = 3,    /* one past the last pass of rsx_sort (default bits/4) */
+    RSX_OPT_LOOKAHEAD = 4     /* 1 (default): inside rsx_sort the reorder of pass p also counts pass p+1's digits per
+                                 output tile, so only the first pass runs the histogram kernel; 0: every pass runs
+                                 histogram -> scan -> paste -> reorder separately.  Results are identical. */
 } rsx_option;
 
 /* Per-phase launch timings in milliseconds, the RuntimesGPU fields

@@ -21,7 +21,7 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libradixsort_hip.so")
+LIB_PATH = os.environ.get("RSX_LIB") or os.path.join(_HERE, "libradixsort_hip.so")   # RSX_LIB: A/B builds while tuning
 
 # OperationStatus (reference src/OperationStatus.h:4-17)
 STATUS_NAMES = [
@@ -30,7 +30,7 @@ STATUS_NAMES = [
     "PROGRAM_CREATION_FAILED", "NO_SOURCE_FOUND", "LOADING_SOURCE_FAILED",
 ]
 
-OPT_PROFILE, OPT_XCD_REMAP, OPT_FIRST_PASS, OPT_LAST_PASS = 0, 1, 2, 3
+OPT_PROFILE, OPT_XCD_REMAP, OPT_FIRST_PASS, OPT_LAST_PASS, OPT_LOOKAHEAD = 0, 1, 2, 3, 4
 
 # every symbol include/radixsort_hip.h declares (tests/test_capi_symbols.py checks the header against this)
 SYMBOLS = [

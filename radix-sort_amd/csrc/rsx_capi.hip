@@ -46,8 +46,14 @@ int fail(int status, const char* what, hipError_t err = hipSuccess)
 
 // Tile geometry.  One compiled shape per key width for now; the table layout
 // depends on it, so it is fixed per engine.
-constexpr int kTileThreads = 256;
-constexpr int kKeysPerThread = 16;
+#ifndef RSX_TILE_THREADS
+#define RSX_TILE_THREADS 256
+#endif
+#ifndef RSX_KPT
+#define RSX_KPT 16
+#endif
+constexpr int kTileThreads = RSX_TILE_THREADS;
+constexpr int kKeysPerThread = RSX_KPT;
 constexpr int kTileKeys = kTileThreads * kKeysPerThread;
 
 enum Phase : int { PH_HISTO = 0, PH_SCAN = 1, PH_PASTE = 2, PH_REORDER = 3, PH_TOTAL = 4, PH_COUNT = 5 };
@@ -97,6 +103,7 @@ struct rsx_engine {
     uint32_t* table = nullptr;                  // "histograms": [digit][tile]
     uint32_t* globsum = nullptr;                // block sums of the table scan
     uint32_t* temp = nullptr;                   // grand total of scan #2
+    uint32_t* counts_next = nullptr;            // look-ahead histogram of the next pass, [tile][digit]
     uint32_t* starts_dev = nullptr;             // 16 bucket starts (rsx_partition)
     uint32_t* starts_host = nullptr;            // pinned mirror
     uint64_t table_cap = 0;
@@ -104,8 +111,9 @@ struct rsx_engine {
     hipStream_t stream = nullptr;
     bool own_stream = false;
 
-    bool profile = false;
+    int profile = 0;            // 0 off, 1 every launch, 2 reorder launches (+ whole sort) only
     int xcd_remap = 1;
+    int lookahead = 1;          // rsx_sort builds pass p+1's histogram inside pass p's reorder
     int first_pass = 0;
     int last_pass = 0;
 
@@ -126,7 +134,7 @@ struct Bracket {   // optional HIP-event pair around one launch (profile mode)
     bool on = false;
     Bracket(rsx_engine* eng, int ph) : e(eng), phase(ph)
     {
-        if (!e->profile) return;
+        if (e->profile == 0 || (e->profile == 2 && ph != PH_REORDER && ph != PH_TOTAL)) return;
         auto take = [&]() -> hipEvent_t {
             if (!e->pool.empty()) {
                 hipEvent_t ev = e->pool.back();
@@ -197,14 +205,21 @@ int launch_histogram(rsx_engine* e, const void* in, uint64_t count, int shift, u
     return RSX_OK;
 }
 
-int launch_scan(rsx_engine* e, uint64_t count)
+int launch_scan(rsx_engine* e, uint64_t count, bool from_counts = false)
 {
     if (count == 0) return RSX_OK;
-    const uint64_t len = static_cast<uint64_t>(RSX_RADIX) * e->ntiles(count);
+    const uint32_t ntiles = static_cast<uint32_t>(e->ntiles(count));
+    const uint64_t len = static_cast<uint64_t>(RSX_RADIX) * ntiles;
     const uint32_t nblocks = static_cast<uint32_t>((len + rsx::kScanBlock - 1) / rsx::kScanBlock);
     {
         Bracket b(e, PH_SCAN);
-        hipLaunchKernelGGL(rsx::scan_blocks_kernel, dim3(nblocks), dim3(rsx::kScanThreads), 0, e->stream, e->table, e->globsum, len);
+        if (from_counts) {
+            hipLaunchKernelGGL(rsx::scan_blocks_kernel<true>, dim3(nblocks), dim3(rsx::kScanThreads), 0, e->stream, e->table, e->globsum,
+                               len, static_cast<const uint32_t*>(e->counts_next), ntiles);
+        } else {
+            hipLaunchKernelGGL(rsx::scan_blocks_kernel<false>, dim3(nblocks), dim3(rsx::kScanThreads), 0, e->stream, e->table, e->globsum,
+                               len, static_cast<const uint32_t*>(nullptr), ntiles);
+        }
     }
     RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
     {
@@ -226,36 +241,44 @@ int launch_paste(rsx_engine* e, uint64_t count)
     return RSX_OK;
 }
 
-template <typename Key, bool PAYLOAD>
+// next_shift < 0: plain reorder.  next_shift >= 0: also count digit (key >> next_shift) & 15 per
+// OUTPUT tile into e->counts_next (zeroed here, on the stream, before the launch).
+template <typename Key, bool PAYLOAD, bool LOOKAHEAD>
 int launch_reorder_t(rsx_engine* e, const void* in, void* out, const uint32_t* pin, uint32_t* pout, uint64_t count, int shift,
-                     uint32_t mask)
+                     uint32_t mask, int next_shift)
 {
     using L = rsx::ReorderLayout<Key, kTileThreads, kKeysPerThread>;
     const Grid g = grid_for(e, count);
+    if (LOOKAHEAD) {
+        RSX_TRY(hipMemsetAsync(e->counts_next, 0, static_cast<size_t>(g.ntiles) * RSX_RADIX * 4, e->stream), RSX_CALCULATION_FAILED);
+    }
     Bracket b(e, PH_REORDER);
-    hipLaunchKernelGGL((rsx::reorder_kernel<Key, kTileThreads, kKeysPerThread, PAYLOAD>), dim3(g.blocks), dim3(kTileThreads),
+    hipLaunchKernelGGL((rsx::reorder_kernel<Key, kTileThreads, kKeysPerThread, PAYLOAD, LOOKAHEAD>), dim3(g.blocks), dim3(kTileThreads),
                        L::BYTES, e->stream, static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->table, count,
-                       g.ntiles, g.tiles_per_xcd, e->xcd_remap, shift, flip_mask<Key>(e), mask);
+                       g.ntiles, g.tiles_per_xcd, e->xcd_remap, shift, flip_mask<Key>(e), mask, e->counts_next, next_shift);
     RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
     return RSX_OK;
 }
 
 template <typename Key>
 int launch_reorder(rsx_engine* e, const void* in, void* out, const uint32_t* pin, uint32_t* pout, uint64_t count, int shift,
-                   uint32_t mask)
+                   uint32_t mask, int next_shift = -1)
 {
     if (count == 0) return RSX_OK;
-    if (pin && pout) {
-        return launch_reorder_t<Key, true>(e, in, out, pin, pout, count, shift, mask);
+    const bool payload = pin && pout;
+    if (next_shift >= 0) {
+        return payload ? launch_reorder_t<Key, true, true>(e, in, out, pin, pout, count, shift, mask, next_shift)
+                       : launch_reorder_t<Key, false, true>(e, in, out, nullptr, nullptr, count, shift, mask, next_shift);
     }
-    return launch_reorder_t<Key, false>(e, in, out, nullptr, nullptr, count, shift, mask);
+    return payload ? launch_reorder_t<Key, true, false>(e, in, out, pin, pout, count, shift, mask, 0)
+                   : launch_reorder_t<Key, false, false>(e, in, out, nullptr, nullptr, count, shift, mask, 0);
 }
 
-template <typename Key, bool PAYLOAD>
+template <typename Key, bool PAYLOAD, bool LOOKAHEAD>
 int allow_lds()
 {
     using L = rsx::ReorderLayout<Key, kTileThreads, kKeysPerThread>;
-    RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder_kernel<Key, kTileThreads, kKeysPerThread, PAYLOAD>),
+    RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder_kernel<Key, kTileThreads, kKeysPerThread, PAYLOAD, LOOKAHEAD>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L::BYTES)),
             RSX_INITIALIZATION_FAILED);
     return RSX_OK;
@@ -284,7 +307,20 @@ int sort_chain(rsx_engine* e, const void* ext_keys, const uint32_t* ext_perm, ui
     for (int pass = e->first_pass; pass < e->last_pass; ++pass) {
         void* out = e->keys[dst];
         uint32_t* pout = e->has_payload ? e->perm[dst] : nullptr;
-        const int rc = run_pass<Key>(e, in, out, pin, pout, count, pass * RSX_RADIX_BITS, RSX_RADIX - 1);
+        const int shift = pass * RSX_RADIX_BITS;
+        int rc;
+        if (!e->lookahead) {
+            rc = run_pass<Key>(e, in, out, pin, pout, count, shift, RSX_RADIX - 1);
+        } else {
+            // only the first pass reads the keys for a histogram; every later table was
+            // counted by the previous pass's reorder while it scattered (look-ahead)
+            const bool first = pass == e->first_pass;
+            rc = first ? launch_histogram<Key>(e, in, count, shift, RSX_RADIX - 1) : RSX_OK;
+            if (rc == RSX_OK) rc = launch_scan(e, count, /*from_counts=*/!first);
+            if (rc == RSX_OK) rc = launch_paste(e, count);
+            const int next_shift = pass + 1 < e->last_pass ? shift + RSX_RADIX_BITS : -1;
+            if (rc == RSX_OK) rc = launch_reorder<Key>(e, in, out, pin, pout, count, shift, RSX_RADIX - 1, next_shift);
+        }
         if (rc != RSX_OK) return rc;
         in = out;
         pin = pout;
@@ -374,6 +410,7 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
     e->last_pass = static_cast<int>(e->passes());
     for (auto& s : e->stats) stat_reset(s);
     if (const char* env = std::getenv("RSX_XCD_REMAP")) e->xcd_remap = std::atoi(env) != 0;
+    if (const char* env = std::getenv("RSX_LOOKAHEAD")) e->lookahead = std::atoi(env) != 0;
 
     auto bail = [&](int status, const char* what, hipError_t err) {
         rsx_destroy(e);
@@ -401,6 +438,8 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
     const size_t table_alloc = ((e->table_cap + rsx::kScanBlock - 1) / rsx::kScanBlock) * rsx::kScanBlock * 4;
     if ((err = hipMalloc(reinterpret_cast<void**>(&e->table), table_alloc)) != hipSuccess)
         return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(histograms)", err);
+    if ((err = hipMalloc(reinterpret_cast<void**>(&e->counts_next), table_alloc)) != hipSuccess)
+        return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(look-ahead counts)", err);
     if ((err = hipMalloc(reinterpret_cast<void**>(&e->globsum), rsx::kMaxScanBlocks * 4)) != hipSuccess)
         return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(globsum)", err);
     if ((err = hipMalloc(reinterpret_cast<void**>(&e->temp), 64)) != hipSuccess)
@@ -413,10 +452,14 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
         return bail(RSX_INITIALIZATION_FAILED, "hipMemsetAsync(globsum)", err);
 
     int rc = RSX_OK;
-    if (rc == RSX_OK) rc = allow_lds<uint32_t, false>();
-    if (rc == RSX_OK) rc = allow_lds<uint32_t, true>();
-    if (rc == RSX_OK) rc = allow_lds<uint64_t, false>();
-    if (rc == RSX_OK) rc = allow_lds<uint64_t, true>();
+    if (rc == RSX_OK) rc = allow_lds<uint32_t, false, false>();
+    if (rc == RSX_OK) rc = allow_lds<uint32_t, true, false>();
+    if (rc == RSX_OK) rc = allow_lds<uint64_t, false, false>();
+    if (rc == RSX_OK) rc = allow_lds<uint64_t, true, false>();
+    if (rc == RSX_OK) rc = allow_lds<uint32_t, false, true>();
+    if (rc == RSX_OK) rc = allow_lds<uint32_t, true, true>();
+    if (rc == RSX_OK) rc = allow_lds<uint64_t, false, true>();
+    if (rc == RSX_OK) rc = allow_lds<uint64_t, true, true>();
     if (rc != RSX_OK) {
         rsx_destroy(e);
         return rc;
@@ -443,6 +486,7 @@ int rsx_destroy(rsx_engine* e)
         if (e->perm[i] && hipFree(e->perm[i]) != hipSuccess) status = RSX_CLEANUP_FAILED;
     }
     if (e->table && hipFree(e->table) != hipSuccess) status = RSX_CLEANUP_FAILED;
+    if (e->counts_next && hipFree(e->counts_next) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->globsum && hipFree(e->globsum) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->temp && hipFree(e->temp) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->starts_dev && hipFree(e->starts_dev) != hipSuccess) status = RSX_CLEANUP_FAILED;
@@ -470,8 +514,9 @@ int rsx_set_option(rsx_engine* e, int option, int64_t value)
 {
     if (!e) return fail(RSX_INITIALIZATION_FAILED, "rsx_set_option: null engine");
     switch (option) {
-    case RSX_OPT_PROFILE: e->profile = value != 0; return RSX_OK;
+    case RSX_OPT_PROFILE: e->profile = value < 0 || value > 2 ? 1 : static_cast<int>(value); return RSX_OK;
     case RSX_OPT_XCD_REMAP: e->xcd_remap = value != 0; return RSX_OK;
+    case RSX_OPT_LOOKAHEAD: e->lookahead = value != 0; return RSX_OK;
     case RSX_OPT_FIRST_PASS:
         if (value < 0 || value > e->passes()) return fail(RSX_CALCULATION_FAILED, "rsx_set_option: first pass out of range");
         e->first_pass = static_cast<int>(value);

@@ -30,6 +30,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// 1 (default): every lane loads its own 16 consecutive keys straight from HBM (64 contiguous
+// bytes per lane, 16-byte loads).  0: 16 B/lane coalesced loads + a transposition through LDS.
+// Measured on MI355X (2^28 uint32): same speed for the plain reorder, 7 % faster for the fused
+// look-ahead reorder (less LDS traffic, one barrier fewer) — see profiles/r01_tuning_log.md.
+#ifndef RSX_DIRECT_LOAD
+#define RSX_DIRECT_LOAD 1
+#endif
+
 namespace rsx {
 
 constexpr int kRadixBits = 4;
@@ -194,15 +202,29 @@ constexpr int kGlobsumThreads = 1024;
 constexpr int kGlobsumPerThread = 4;
 constexpr int kMaxScanBlocks = kGlobsumThreads * kGlobsumPerThread;   // 4096 block sums
 
-// scan #1: exclusive scan inside every block of 4096 entries, block total -> globsum[block]
+// scan #1: exclusive scan inside every block of 4096 entries, block total -> globsum[block].
+// FROM_COUNTS: the raw counts come from the look-ahead buffer in [tile][digit] layout and
+// are gathered into the digit-major order of the table on the fly.
+template <bool FROM_COUNTS>
 __global__ __launch_bounds__(kScanThreads) void scan_blocks_kernel(uint32_t* __restrict__ table, uint32_t* __restrict__ globsum,
-                                                                    uint64_t len)
+                                                                    uint64_t len, const uint32_t* __restrict__ counts, uint32_t ntiles)
 {
     __shared__ uint32_t wtot[kScanThreads / kWave];
     const uint32_t tid = threadIdx.x;
     const uint64_t first = static_cast<uint64_t>(blockIdx.x) * kScanBlock + static_cast<uint64_t>(tid) * kScanPerThread;
     uint32_t v[kScanPerThread];
-    if (first + kScanPerThread <= len) {
+    if constexpr (FROM_COUNTS) {
+        uint32_t d = static_cast<uint32_t>(first / ntiles);
+        uint32_t t = static_cast<uint32_t>(first - static_cast<uint64_t>(d) * ntiles);
+#pragma unroll
+        for (int i = 0; i < kScanPerThread; ++i) {
+            v[i] = (first + i < len) ? counts[static_cast<uint64_t>(t) * kRadix + d] : 0u;
+            if (++t == ntiles) {
+                t = 0;
+                ++d;
+            }
+        }
+    } else if (first + kScanPerThread <= len) {
 #pragma unroll
         for (int q = 0; q < kScanPerThread / 4; ++q) {
             const U32x4 x = *reinterpret_cast<const U32x4*>(table + first + q * 4);
@@ -316,6 +338,33 @@ __global__ __launch_bounds__(kScanThreads) void paste_kernel(uint32_t* __restric
 //           (d<8) or high (d>=8) 16 bits
 //   wtot  : wave totals of the raking scan
 //   gbase : per digit, (global slot of the tile's first key of that digit) - (its local slot)
+// One key's contribution to the look-ahead counters.  All 64 lanes call this together.
+// If the whole wave hits one counter (single-digit data: Zeros, Range) one lane adds 64
+// instead of 64 lanes serialising on one LDS address.
+struct alignas(8) RunBase {
+    uint32_t gbase;      // (global slot of the tile's first key of this digit) - (its tile-local slot)
+    uint32_t run_tile;   // output tile that global slot falls in
+};
+
+// Look-ahead histogram: one key's contribution to la[(digit, segment)][next digit].
+// `idx` is the counter index (kLaDummy for a slot that holds no key).  On random data the 64
+// lanes of a wave spread over 16 counters (4 lanes each) and simply add 1.  When the whole
+// wave targets ONE counter (constant or sorted data: every pass of Zeros, most passes of
+// Range) the uniform branch lets lane 0 add 64 instead of 64 lanes serialising on one address.
+constexpr uint32_t kLaDummy = 2 * kRadix * kRadix;   // one spare counter past the 512 real ones
+
+__device__ __forceinline__ void lookahead_count(uint32_t* la, uint32_t idx)
+{
+    const uint32_t first = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(idx)));
+    if (__builtin_expect(__ballot(idx != first) == 0ull, 0)) {
+        if ((threadIdx.x & (kWave - 1)) == 0) {
+            atomicAdd(&la[first], static_cast<uint32_t>(kWave));
+        }
+    } else {
+        atomicAdd(&la[idx], 1u);
+    }
+}
+
 template <typename Key, int THREADS, int KPT>
 struct ReorderLayout {
     static constexpr int TILE = THREADS * KPT;
@@ -323,21 +372,49 @@ struct ReorderLayout {
     static constexpr int ROW_DW = KPT * KD + 4;
     static constexpr int PADSH = (KD == 1) ? 5 : 4;
     static constexpr int XELEMS = TILE + (TILE >> PADSH);
+#if RSX_DIRECT_LOAD
+    static constexpr int XBUF_DW = XELEMS * KD;             // no transposition image
+#else
     static constexpr int XBUF_DW = (THREADS * ROW_DW > XELEMS * KD) ? THREADS * ROW_DW : XELEMS * KD;
+#endif
     static constexpr int CNT_DW = 8 * THREADS;
     static constexpr int WTOT_DW = 16;
-    static constexpr int GBASE_DW = kRadix;
-    static constexpr int TOTAL_DW = XBUF_DW + CNT_DW + WTOT_DW + GBASE_DW;
+    static constexpr int GBASE_DW = 2 * kRadix;             // per digit {gbase, first output tile of the run}: one ds_read_b64
+    static constexpr int LA_DW = kRadix * 2 * kRadix + 16;  // look-ahead counters [digit][segment 0/1][next digit] + dummy
+    static constexpr int TOTAL_DW = XBUF_DW + CNT_DW + WTOT_DW + GBASE_DW + LA_DW;
+    static constexpr int TILE_SHIFT = __builtin_ctz(TILE);
+    static_assert((TILE & (TILE - 1)) == 0, "tile size must be a power of two (slot -> output tile by shift)");
     static constexpr size_t BYTES = static_cast<size_t>(TOTAL_DW) * 4;
+    // Workgroups one CU can hold by LDS (160 KiB) -> waves per SIMD the register allocator must
+    // leave room for (second __launch_bounds__ argument = waves per SIMD, not blocks per CU).
+    static constexpr int WGS_PER_CU = static_cast<int>((160 * 1024) / BYTES);
+    static constexpr int MIN_WAVES = (WGS_PER_CU * THREADS / 256) > 8 ? 8 : (WGS_PER_CU * THREADS / 256);
     static_assert(TILE <= 32768, "16-bit packed counters");
     static_assert(KPT % (16 / sizeof(Key)) == 0 && THREADS % 64 == 0 && THREADS % 8 == 0, "geometry");
 };
 
+// Register budget: keys-only kernels are held to the occupancy LDS allows; payload kernels carry
+// twice the per-key state (key, slot, payload, target) and are given 128 VGPRs instead of spilling.
 template <typename Key, int THREADS, int KPT, bool PAYLOAD>
-__global__ __launch_bounds__(THREADS) void reorder_kernel(const Key* __restrict__ in, Key* __restrict__ out,
+constexpr int reorder_min_waves()
+{
+    constexpr int w = ReorderLayout<Key, THREADS, KPT>::MIN_WAVES;
+    constexpr int cap = 4 * THREADS / 256;
+    return (PAYLOAD && w > cap) ? cap : w;
+}
+
+// LOOKAHEAD: while a key leaves for its slot g, the kernel also counts the key's NEXT
+// digit for the output tile g / TILE — i.e. it builds the next pass's per-tile histogram
+// (layout [tile][digit] in `next_counts`, zeroed by the host) without another pass over
+// HBM.  A run (one digit of one source tile) covers at most two output tiles, so the
+// counts are first gathered in LDS as [digit][segment 0/1][next digit] and then flushed
+// with one global atomic per non-zero counter (16 consecutive lanes -> one 64-B segment).
+template <typename Key, int THREADS, int KPT, bool PAYLOAD, bool LOOKAHEAD>
+__global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYLOAD>())) void reorder_kernel(const Key* __restrict__ in, Key* __restrict__ out,
                                                            const uint32_t* __restrict__ pin, uint32_t* __restrict__ pout,
                                                            const uint32_t* __restrict__ table, uint64_t n, uint32_t ntiles,
-                                                           uint32_t tiles_per_xcd, int remap, int shift, Key flip, uint32_t mask)
+                                                           uint32_t tiles_per_xcd, int remap, int shift, Key flip, uint32_t mask,
+                                                           uint32_t* __restrict__ next_counts, int next_shift)
 {
     using L = ReorderLayout<Key, THREADS, KPT>;
     constexpr int TILE = L::TILE;
@@ -349,7 +426,8 @@ __global__ __launch_bounds__(THREADS) void reorder_kernel(const Key* __restrict_
     uint32_t* xbuf = smem;
     uint32_t* cnt = smem + L::XBUF_DW;
     uint32_t* wtot = cnt + L::CNT_DW;
-    uint32_t* gbase = wtot + L::WTOT_DW;
+    RunBase* runs = reinterpret_cast<RunBase*>(wtot + L::WTOT_DW);
+    uint32_t* la = wtot + L::WTOT_DW + L::GBASE_DW;
 
     const uint32_t tid = threadIdx.x;
     const uint32_t tile = tile_of_block(blockIdx.x, tiles_per_xcd, remap);
@@ -364,13 +442,39 @@ __global__ __launch_bounds__(THREADS) void reorder_kernel(const Key* __restrict_
     // order as well they land in local slots [valid, TILE) and are never stored.
     const Key pad_key = static_cast<Key>(~flip);
 
-    // table[d][tile] for d = tid < 16, issued first so its latency hides under the key loads
-    uint32_t my_first_slot = 0;
-    if (tid < kRadix) {
-        my_first_slot = table[static_cast<uint64_t>(tid) * ntiles + tile];
+    // The 8 raking threads whose first scan word belongs to thread 0 (digits hl and hl+8)
+    // fetch table[digit][tile] for those two digits now, so the latency hides under the key loads.
+    constexpr uint32_t RAKE_STRIDE = THREADS / 8;
+    const bool rake_head = (tid % RAKE_STRIDE) == 0;
+    const uint32_t hl = tid / RAKE_STRIDE;
+    uint32_t first_lo = 0, first_hi = 0;
+    if (rake_head) {
+        first_lo = table[static_cast<uint64_t>(hl) * ntiles + tile];
+        first_hi = table[static_cast<uint64_t>(hl + 8) * ntiles + tile];
     }
 
     // ---- 1. coalesced load (striped, 16 B per lane) -> LDS rows (blocked) ----------
+    Key k[KPT];
+#if RSX_DIRECT_LOAD
+    // Variant: every lane fetches its own 16 consecutive keys (64 contiguous bytes) with
+    // 16-byte loads and no LDS transposition; lines are shared by 2 lanes per instruction.
+    if (full) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const KeyVec<Key> v = *reinterpret_cast<const KeyVec<Key>*>(in + base + tid * KPT + j * VEC);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                k[j * VEC + e] = v.k[e];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const uint32_t li = tid * KPT + i;
+            k[i] = li < valid ? in[base + li] : pad_key;
+        }
+    }
+#else
     {
         KeyVec<Key> v[NV];
         if (full) {
@@ -396,6 +500,7 @@ __global__ __launch_bounds__(THREADS) void reorder_kernel(const Key* __restrict_
             *reinterpret_cast<KeyVec<Key>*>(xbuf + owner * L::ROW_DW + within * KD) = v[j];
         }
     }
+#endif
     // payload of the thread's blocked keys straight from HBM (64 B contiguous per lane)
     uint32_t pl[PAYLOAD ? KPT : 1];
     if constexpr (PAYLOAD) {
@@ -416,10 +521,12 @@ __global__ __launch_bounds__(THREADS) void reorder_kernel(const Key* __restrict_
             }
         }
     }
+#if !RSX_DIRECT_LOAD
     __syncthreads();
+#endif
 
     // ---- 2. each thread = one virtual processor: KPT consecutive keys, private counters
-    Key k[KPT];
+#if !RSX_DIRECT_LOAD
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const KeyVec<Key> v = *reinterpret_cast<const KeyVec<Key>*>(xbuf + tid * L::ROW_DW + j * VEC * KD);
@@ -428,21 +535,27 @@ __global__ __launch_bounds__(THREADS) void reorder_kernel(const Key* __restrict_
             k[j * VEC + e] = v.k[e];
         }
     }
+#endif
     u16_alias* cnt16 = reinterpret_cast<u16_alias*>(cnt);
+    u32_alias* cnt32 = reinterpret_cast<u32_alias*>(cnt);
 #pragma unroll
     for (int l = 0; l < 8; ++l) {
-        cnt16[(l * THREADS + tid) * 2 + 0] = 0;
-        cnt16[(l * THREADS + tid) * 2 + 1] = 0;
+        cnt32[l * THREADS + tid] = 0;
+    }
+    if constexpr (LOOKAHEAD) {
+        for (uint32_t c = tid; c < static_cast<uint32_t>(L::LA_DW); c += THREADS) {
+            la[c] = 0;
+        }
     }
     uint32_t slot[KPT];      // first: rank among the thread's own equal-digit keys; later: tile-local slot
-    uint32_t cidx[KPT];      // index of the key's 16-bit counter
+    // 16-bit counter of (digit d, this thread): word [d&7][tid], half d>>3
+    auto counter_index = [tid](uint32_t d) { return (((d & 7u) * THREADS + tid) << 1) + (d >> 3); };
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
-        const uint32_t d = digit_of(k[i], shift, flip, mask);
-        cidx[i] = (((d & 7u) * THREADS + tid) << 1) + (d >> 3);
-        const uint32_t c = cnt16[cidx[i]];
+        const uint32_t ci = counter_index(digit_of(k[i], shift, flip, mask));
+        const uint32_t c = cnt16[ci];
         slot[i] = c;
-        cnt16[cidx[i]] = static_cast<uint16_t>(c + 1);
+        cnt16[ci] = static_cast<uint16_t>(c + 1);
     }
     __syncthreads();
 
@@ -456,6 +569,12 @@ __global__ __launch_bounds__(THREADS) void reorder_kernel(const Key* __restrict_
         // low halves now prefix digits 0..7, high halves digits 8..15; the latter start
         // after ALL keys with digit < 8, i.e. after total.low
         run += total << 16;
+        if (rake_head) {
+            // `run` is the scanned word of (digit hl | hl+8, thread 0): the tile-local slot of
+            // the tile's first key with that digit
+            runs[hl] = RunBase{first_lo - (run & 0xFFFFu), first_lo >> L::TILE_SHIFT};
+            runs[hl + 8] = RunBase{first_hi - (run >> 16), first_hi >> L::TILE_SHIFT};
+        }
         uint32_t t;
         t = a.v[0]; a.v[0] = run; run += t;
         t = a.v[1]; a.v[1] = run; run += t;
@@ -471,40 +590,56 @@ __global__ __launch_bounds__(THREADS) void reorder_kernel(const Key* __restrict_
     __syncthreads();
 
     // ---- 4. tile-local slot of every key; stage the tile in sorted order -------------
-    if (tid < kRadix) {
-        // thread 0's scanned counter of digit `tid` = local slot of the tile's first such key
-        const uint32_t local_first = cnt16[(((tid & 7u) * THREADS) << 1) + (tid >> 3)];
-        gbase[tid] = my_first_slot - local_first;
-    }
+    // Written as "all reads, then all writes" on purpose: the compiler cannot prove that the
+    // staging writes do not alias the counters, so a fused loop waits for every LDS read
+    // before the next one is issued (16 exposed LDS latencies instead of one).
     Key* xk = reinterpret_cast<Key*>(xbuf);
+    {
+        uint32_t first_of_digit[KPT];
 #pragma unroll
-    for (int i = 0; i < KPT; ++i) {
-        slot[i] += cnt16[cidx[i]];
-        xk[slot[i] + (slot[i] >> L::PADSH)] = k[i];
+        for (int i = 0; i < KPT; ++i) {
+            first_of_digit[i] = cnt16[counter_index(digit_of(k[i], shift, flip, mask))];
+        }
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            slot[i] += first_of_digit[i];
+        }
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            xk[slot[i] + (slot[i] >> L::PADSH)] = k[i];
+        }
     }
     __syncthreads();
 
     // ---- 5. leave as runs: consecutive lanes -> consecutive addresses inside a run ---
-    if constexpr (!PAYLOAD) {
+    // Same batching: 16 key reads in flight, then 16 run-base reads, then 16 stores.
+    Key okey[KPT];
+    uint32_t g[KPT];
+    uint32_t la_idx[LOOKAHEAD ? KPT : 1];
+#pragma unroll
+    for (int r = 0; r < KPT; ++r) {
+        const uint32_t i = static_cast<uint32_t>(r) * THREADS + tid;
+        okey[r] = xk[i + (i >> L::PADSH)];
+    }
+    {
+        RunBase rb[KPT];
+#pragma unroll
+        for (int r = 0; r < KPT; ++r) {
+            rb[r] = runs[digit_of(okey[r], shift, flip, mask)];
+        }
 #pragma unroll
         for (int r = 0; r < KPT; ++r) {
             const uint32_t i = static_cast<uint32_t>(r) * THREADS + tid;
-            const Key key = xk[i + (i >> L::PADSH)];
-            const uint32_t g = gbase[digit_of(key, shift, flip, mask)] + i;
-            if (full || i < valid) {
-                out[g] = key;
+            g[r] = rb[r].gbase + i;
+            if constexpr (LOOKAHEAD) {
+                la_idx[r] = (digit_of(okey[r], shift, flip, mask) << 5) + (((g[r] >> L::TILE_SHIFT) - rb[r].run_tile) << 4) +
+                            digit_of(okey[r], next_shift, flip, static_cast<uint32_t>(kRadix - 1));
             }
         }
-    } else {
-        Key okey[KPT];
-        uint32_t g[KPT];
-#pragma unroll
-        for (int r = 0; r < KPT; ++r) {
-            const uint32_t i = static_cast<uint32_t>(r) * THREADS + tid;
-            okey[r] = xk[i + (i >> L::PADSH)];
-            g[r] = gbase[digit_of(okey[r], shift, flip, mask)] + i;
-        }
-        __syncthreads();
+    }
+    uint32_t pay[PAYLOAD ? KPT : 1];
+    if constexpr (PAYLOAD) {
+        __syncthreads();      // every wave has read its keys: the image may be overwritten
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
             xbuf[slot[i] + (slot[i] >> 5)] = pl[i];
@@ -513,10 +648,42 @@ __global__ __launch_bounds__(THREADS) void reorder_kernel(const Key* __restrict_
 #pragma unroll
         for (int r = 0; r < KPT; ++r) {
             const uint32_t i = static_cast<uint32_t>(r) * THREADS + tid;
-            const uint32_t p = xbuf[i + (i >> 5)];
-            if (full || i < valid) {
+            pay[r] = xbuf[i + (i >> 5)];
+        }
+    }
+    if (full) {
+#pragma unroll
+        for (int r = 0; r < KPT; ++r) {
+            out[g[r]] = okey[r];
+            if constexpr (PAYLOAD) {
+                pout[g[r]] = pay[r];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < KPT; ++r) {
+            const uint32_t i = static_cast<uint32_t>(r) * THREADS + tid;
+            if (i < valid) {
                 out[g[r]] = okey[r];
-                pout[g[r]] = p;
+                if constexpr (PAYLOAD) {
+                    pout[g[r]] = pay[r];
+                }
+            } else if constexpr (LOOKAHEAD) {
+                la_idx[r] = kLaDummy;
+            }
+        }
+    }
+    if constexpr (LOOKAHEAD) {
+#pragma unroll
+        for (int r = 0; r < KPT; ++r) {
+            lookahead_count(la, la_idx[r]);
+        }
+        __syncthreads();
+        for (uint32_t c = tid; c < kLaDummy; c += THREADS) {
+            const uint32_t v = la[c];
+            if (v) {
+                const uint32_t d = c >> 5, seg = (c >> 4) & 1u, d2 = c & 15u;
+                atomicAdd(&next_counts[static_cast<uint64_t>(runs[d].run_tile + seg) * kRadix + d2], v);
             }
         }
     }

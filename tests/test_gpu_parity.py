@@ -174,6 +174,30 @@ def test_xcd_remap_does_not_change_results(mod, oracle):
     assert np.array_equal(outs[0], np.sort(keys))
 
 
+@pytest.mark.parametrize("dt,n,payload", [("uint32", 1 << 20, False), ("int32", 99991, True), ("uint64", 262147, False),
+                                          ("int64", 4097, True), ("uint32", 4096, False), ("uint32", 5, True)])
+@pytest.mark.parametrize("kind", ["SeededUniform", "Zeros", "InvertedRange"])
+def test_lookahead_histogram_equals_separate_histogram_passes(mod, oracle, dt, n, payload, kind):
+    """rsx_sort's fused path (reorder of pass p counts pass p+1's digits per output tile)
+    against the plain histogram -> scan -> paste -> reorder loop: identical bytes, and the
+    last pass's scanned table is identical too."""
+    keys = oracle.dataset(kind, dt, n)
+    perm = np.arange(n, dtype=np.uint32) if payload else None
+    outs = []
+    for la in (0, 1):
+        with mod.Engine(dt, n, payload=payload) as e:
+            e.set_option(mod.OPT_LOOKAHEAD, la)
+            e.upload(keys, perm)
+            e.sort()
+            ntab = 16 * e.geometry().num_tiles
+            outs.append(e.download(want_perm=payload, hist_cap=ntab))
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(outs[1][0], np.sort(keys))
+    if payload:
+        assert np.array_equal(outs[1][1], np.argsort(keys, kind="stable").astype(np.uint32))
+
+
 # --------------------------------------------------------------------------- reference semantics
 def test_fill_pad_value_and_rounded_length(mod, oracle):
     """padGPUData writes max()-1 from a byte offset (RadixSortGPU.cpp:270-285); the sort
@@ -214,6 +238,12 @@ def test_timings_profile_mode(mod, oracle):
     keys = oracle.dataset("Random", "uint32", 1 << 20)
     with mod.Engine("uint32", keys.size) as e:
         e.set_option(mod.OPT_PROFILE, 1)
+        e.upload(keys)
+        e.sort()
+        t = e.timings(reset=True)
+        assert t.histogram.n == 1 and t.reorder.n == 8 and t.paste.n == 8      # look-ahead: one histogram launch
+        assert np.array_equal(e.download(), np.sort(keys))
+        e.set_option(mod.OPT_LOOKAHEAD, 0)
         e.upload(keys)
         e.sort()
         t = e.timings()
