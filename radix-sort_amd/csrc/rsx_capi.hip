@@ -114,6 +114,8 @@ struct rsx_engine {
     int profile = 0;            // 0 off, 1 every launch, 2 reorder launches (+ whole sort) only
     int xcd_remap = 1;
     int lookahead = 1;          // rsx_sort builds pass p+1's histogram inside pass p's reorder
+    int fold_paste = 0;         // reorder adds globsum itself (no paste launch): measured 3 % slower, off; env RSX_FOLD_PASTE
+    int scan_zeroes = 1;
     int first_pass = 0;
     int last_pass = 0;
 
@@ -213,12 +215,15 @@ int launch_scan(rsx_engine* e, uint64_t count, bool from_counts = false)
     const uint32_t nblocks = static_cast<uint32_t>((len + rsx::kScanBlock - 1) / rsx::kScanBlock);
     {
         Bracket b(e, PH_SCAN);
-        if (from_counts) {
-            hipLaunchKernelGGL(rsx::scan_blocks_kernel<true>, dim3(nblocks), dim3(rsx::kScanThreads), 0, e->stream, e->table, e->globsum,
-                               len, static_cast<const uint32_t*>(e->counts_next), ntiles);
+        if (from_counts && e->scan_zeroes) {
+            hipLaunchKernelGGL((rsx::scan_blocks_kernel<true, true>), dim3(nblocks), dim3(rsx::kScanThreads), 0, e->stream, e->table, e->globsum,
+                               len, e->counts_next, ntiles);
+        } else if (from_counts) {
+            hipLaunchKernelGGL((rsx::scan_blocks_kernel<true, false>), dim3(nblocks), dim3(rsx::kScanThreads), 0, e->stream, e->table, e->globsum,
+                               len, e->counts_next, ntiles);
         } else {
-            hipLaunchKernelGGL(rsx::scan_blocks_kernel<false>, dim3(nblocks), dim3(rsx::kScanThreads), 0, e->stream, e->table, e->globsum,
-                               len, static_cast<const uint32_t*>(nullptr), ntiles);
+            hipLaunchKernelGGL((rsx::scan_blocks_kernel<false, false>), dim3(nblocks), dim3(rsx::kScanThreads), 0, e->stream, e->table, e->globsum,
+                               len, static_cast<uint32_t*>(nullptr), ntiles);
         }
     }
     RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
@@ -242,36 +247,36 @@ int launch_paste(rsx_engine* e, uint64_t count)
 }
 
 // next_shift < 0: plain reorder.  next_shift >= 0: also count digit (key >> next_shift) & 15 per
-// OUTPUT tile into e->counts_next (zeroed here, on the stream, before the launch).
+// OUTPUT tile into e->counts_next (all zero on entry: zeroed at the start of the sort and handed
+// back zeroed by the scan that consumes it).  fold_paste: the table holds block-local prefixes
+// and the kernel adds the scanned block sums itself (no paste launch).
 template <typename Key, bool PAYLOAD, bool LOOKAHEAD>
 int launch_reorder_t(rsx_engine* e, const void* in, void* out, const uint32_t* pin, uint32_t* pout, uint64_t count, int shift,
-                     uint32_t mask, int next_shift)
+                     uint32_t mask, int next_shift, bool fold_paste)
 {
     using L = rsx::ReorderLayout<Key, kTileThreads, kKeysPerThread>;
     const Grid g = grid_for(e, count);
-    if (LOOKAHEAD) {
-        RSX_TRY(hipMemsetAsync(e->counts_next, 0, static_cast<size_t>(g.ntiles) * RSX_RADIX * 4, e->stream), RSX_CALCULATION_FAILED);
-    }
     Bracket b(e, PH_REORDER);
     hipLaunchKernelGGL((rsx::reorder_kernel<Key, kTileThreads, kKeysPerThread, PAYLOAD, LOOKAHEAD>), dim3(g.blocks), dim3(kTileThreads),
                        L::BYTES, e->stream, static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->table, count,
-                       g.ntiles, g.tiles_per_xcd, e->xcd_remap, shift, flip_mask<Key>(e), mask, e->counts_next, next_shift);
+                       g.ntiles, g.tiles_per_xcd, e->xcd_remap, shift, flip_mask<Key>(e), mask, e->counts_next, next_shift,
+                       fold_paste ? static_cast<const uint32_t*>(e->globsum) : static_cast<const uint32_t*>(nullptr));
     RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
     return RSX_OK;
 }
 
 template <typename Key>
 int launch_reorder(rsx_engine* e, const void* in, void* out, const uint32_t* pin, uint32_t* pout, uint64_t count, int shift,
-                   uint32_t mask, int next_shift = -1)
+                   uint32_t mask, int next_shift = -1, bool fold_paste = false)
 {
     if (count == 0) return RSX_OK;
     const bool payload = pin && pout;
     if (next_shift >= 0) {
-        return payload ? launch_reorder_t<Key, true, true>(e, in, out, pin, pout, count, shift, mask, next_shift)
-                       : launch_reorder_t<Key, false, true>(e, in, out, nullptr, nullptr, count, shift, mask, next_shift);
+        return payload ? launch_reorder_t<Key, true, true>(e, in, out, pin, pout, count, shift, mask, next_shift, fold_paste)
+                       : launch_reorder_t<Key, false, true>(e, in, out, nullptr, nullptr, count, shift, mask, next_shift, fold_paste);
     }
-    return payload ? launch_reorder_t<Key, true, false>(e, in, out, pin, pout, count, shift, mask, 0)
-                   : launch_reorder_t<Key, false, false>(e, in, out, nullptr, nullptr, count, shift, mask, 0);
+    return payload ? launch_reorder_t<Key, true, false>(e, in, out, pin, pout, count, shift, mask, 0, fold_paste)
+                   : launch_reorder_t<Key, false, false>(e, in, out, nullptr, nullptr, count, shift, mask, 0, fold_paste);
 }
 
 template <typename Key, bool PAYLOAD, bool LOOKAHEAD>
@@ -304,6 +309,10 @@ int sort_chain(rsx_engine* e, const void* ext_keys, const uint32_t* ext_perm, ui
     const uint32_t* pin = e->has_payload ? (ext_keys ? ext_perm : e->perm[e->cur]) : nullptr;
     int dst = ext_keys ? e->cur : (e->cur ^ 1);
     Bracket whole(e, PH_TOTAL);
+    if (e->lookahead && count > 0) {
+        // look-ahead counters start from zero (a previous sort that failed midway may have left some)
+        RSX_TRY(hipMemsetAsync(e->counts_next, 0, static_cast<size_t>(e->ntiles(count)) * RSX_RADIX * 4, e->stream), RSX_CALCULATION_FAILED);
+    }
     for (int pass = e->first_pass; pass < e->last_pass; ++pass) {
         void* out = e->keys[dst];
         uint32_t* pout = e->has_payload ? e->perm[dst] : nullptr;
@@ -317,9 +326,17 @@ int sort_chain(rsx_engine* e, const void* ext_keys, const uint32_t* ext_perm, ui
             const bool first = pass == e->first_pass;
             rc = first ? launch_histogram<Key>(e, in, count, shift, RSX_RADIX - 1) : RSX_OK;
             if (rc == RSX_OK) rc = launch_scan(e, count, /*from_counts=*/!first);
-            if (rc == RSX_OK) rc = launch_paste(e, count);
-            const int next_shift = pass + 1 < e->last_pass ? shift + RSX_RADIX_BITS : -1;
-            if (rc == RSX_OK) rc = launch_reorder<Key>(e, in, out, pin, pout, count, shift, RSX_RADIX - 1, next_shift);
+            // PasteHistogram is folded into the reorder (it adds globsum[block] to the 16 table
+            // entries it reads); only the last pass runs the paste kernel, so that the table a
+            // caller downloads afterwards is the fully pasted one in either mode
+            const bool last = pass + 1 == e->last_pass;
+            const bool fold = e->fold_paste && !last;
+            if (rc == RSX_OK && !fold) rc = launch_paste(e, count);
+            const int next_shift = last ? -1 : shift + RSX_RADIX_BITS;
+            if (rc == RSX_OK && !last && !e->scan_zeroes) {
+                if (hipMemsetAsync(e->counts_next, 0, static_cast<size_t>(e->ntiles(count)) * RSX_RADIX * 4, e->stream) != hipSuccess) rc = RSX_CALCULATION_FAILED;
+            }
+            if (rc == RSX_OK) rc = launch_reorder<Key>(e, in, out, pin, pout, count, shift, RSX_RADIX - 1, next_shift, fold);
         }
         if (rc != RSX_OK) return rc;
         in = out;
@@ -411,6 +428,8 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
     for (auto& s : e->stats) stat_reset(s);
     if (const char* env = std::getenv("RSX_XCD_REMAP")) e->xcd_remap = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_LOOKAHEAD")) e->lookahead = std::atoi(env) != 0;
+    if (const char* env = std::getenv("RSX_FOLD_PASTE")) e->fold_paste = std::atoi(env) != 0;
+    if (const char* env = std::getenv("RSX_SCAN_ZEROES")) e->scan_zeroes = std::atoi(env) != 0;
 
     auto bail = [&](int status, const char* what, hipError_t err) {
         rsx_destroy(e);

@@ -205,9 +205,9 @@ constexpr int kMaxScanBlocks = kGlobsumThreads * kGlobsumPerThread;   // 4096 bl
 // scan #1: exclusive scan inside every block of 4096 entries, block total -> globsum[block].
 // FROM_COUNTS: the raw counts come from the look-ahead buffer in [tile][digit] layout and
 // are gathered into the digit-major order of the table on the fly.
-template <bool FROM_COUNTS>
+template <bool FROM_COUNTS, bool ZERO_BACK = true>
 __global__ __launch_bounds__(kScanThreads) void scan_blocks_kernel(uint32_t* __restrict__ table, uint32_t* __restrict__ globsum,
-                                                                    uint64_t len, const uint32_t* __restrict__ counts, uint32_t ntiles)
+                                                                    uint64_t len, uint32_t* __restrict__ counts, uint32_t ntiles)
 {
     __shared__ uint32_t wtot[kScanThreads / kWave];
     const uint32_t tid = threadIdx.x;
@@ -218,7 +218,17 @@ __global__ __launch_bounds__(kScanThreads) void scan_blocks_kernel(uint32_t* __r
         uint32_t t = static_cast<uint32_t>(first - static_cast<uint64_t>(d) * ntiles);
 #pragma unroll
         for (int i = 0; i < kScanPerThread; ++i) {
-            v[i] = (first + i < len) ? counts[static_cast<uint64_t>(t) * kRadix + d] : 0u;
+            if (first + i < len) {
+                // every counter is read by exactly one thread: hand it back zeroed, so the next
+                // look-ahead pass needs no memset
+                uint32_t* c = counts + static_cast<uint64_t>(t) * kRadix + d;
+                v[i] = *c;
+                if constexpr (ZERO_BACK) {
+                    *c = 0u;
+                }
+            } else {
+                v[i] = 0u;
+            }
             if (++t == ntiles) {
                 t = 0;
                 ++d;
@@ -414,7 +424,8 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
                                                            const uint32_t* __restrict__ pin, uint32_t* __restrict__ pout,
                                                            const uint32_t* __restrict__ table, uint64_t n, uint32_t ntiles,
                                                            uint32_t tiles_per_xcd, int remap, int shift, Key flip, uint32_t mask,
-                                                           uint32_t* __restrict__ next_counts, int next_shift)
+                                                           uint32_t* __restrict__ next_counts, int next_shift,
+                                                           const uint32_t* __restrict__ globsum)
 {
     using L = ReorderLayout<Key, THREADS, KPT>;
     constexpr int TILE = L::TILE;
@@ -449,8 +460,16 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
     const uint32_t hl = tid / RAKE_STRIDE;
     uint32_t first_lo = 0, first_hi = 0;
     if (rake_head) {
-        first_lo = table[static_cast<uint64_t>(hl) * ntiles + tile];
-        first_hi = table[static_cast<uint64_t>(hl + 8) * ntiles + tile];
+        const uint64_t e_lo = static_cast<uint64_t>(hl) * ntiles + tile;
+        const uint64_t e_hi = static_cast<uint64_t>(hl + 8) * ntiles + tile;
+        first_lo = table[e_lo];
+        first_hi = table[e_hi];
+        if (globsum) {
+            // PasteHistogram folded in: the table holds block-local prefixes, add the scanned
+            // sum of the 4096-entry scan block each entry lives in (RadixSort.cl:185-197)
+            first_lo += globsum[e_lo / kScanBlock];
+            first_hi += globsum[e_hi / kScanBlock];
+        }
     }
 
     // ---- 1. coalesced load (striped, 16 B per lane) -> LDS rows (blocked) ----------

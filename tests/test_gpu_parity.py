@@ -242,6 +242,7 @@ def test_timings_profile_mode(mod, oracle):
         e.sort()
         t = e.timings(reset=True)
         assert t.histogram.n == 1 and t.reorder.n == 8 and t.paste.n == 8      # look-ahead: one histogram launch
+        assert t.scan.n == 16
         assert np.array_equal(e.download(), np.sort(keys))
         e.set_option(mod.OPT_LOOKAHEAD, 0)
         e.upload(keys)
