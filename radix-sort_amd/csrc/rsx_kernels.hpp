@@ -656,27 +656,12 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
             }
         }
     }
-    uint32_t pay[PAYLOAD ? KPT : 1];
-    if constexpr (PAYLOAD) {
-        __syncthreads();      // every wave has read its keys: the image may be overwritten
-#pragma unroll
-        for (int i = 0; i < KPT; ++i) {
-            xbuf[slot[i] + (slot[i] >> 5)] = pl[i];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < KPT; ++r) {
-            const uint32_t i = static_cast<uint32_t>(r) * THREADS + tid;
-            pay[r] = xbuf[i + (i >> 5)];
-        }
-    }
+    // keys leave first, then the look-ahead counts: both free their registers before the
+    // payload takes its own trip through the staging image
     if (full) {
 #pragma unroll
         for (int r = 0; r < KPT; ++r) {
             out[g[r]] = okey[r];
-            if constexpr (PAYLOAD) {
-                pout[g[r]] = pay[r];
-            }
         }
     } else {
 #pragma unroll
@@ -684,9 +669,6 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
             const uint32_t i = static_cast<uint32_t>(r) * THREADS + tid;
             if (i < valid) {
                 out[g[r]] = okey[r];
-                if constexpr (PAYLOAD) {
-                    pout[g[r]] = pay[r];
-                }
             } else if constexpr (LOOKAHEAD) {
                 la_idx[r] = kLaDummy;
             }
@@ -697,6 +679,29 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
         for (int r = 0; r < KPT; ++r) {
             lookahead_count(la, la_idx[r]);
         }
+    }
+    if constexpr (PAYLOAD) {
+        __syncthreads();      // every wave has read its keys: the image may be overwritten
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            xbuf[slot[i] + (slot[i] >> 5)] = pl[i];
+        }
+        __syncthreads();
+        uint32_t pay[KPT];
+#pragma unroll
+        for (int r = 0; r < KPT; ++r) {
+            const uint32_t i = static_cast<uint32_t>(r) * THREADS + tid;
+            pay[r] = xbuf[i + (i >> 5)];
+        }
+#pragma unroll
+        for (int r = 0; r < KPT; ++r) {
+            const uint32_t i = static_cast<uint32_t>(r) * THREADS + tid;
+            if (full || i < valid) {
+                pout[g[r]] = pay[r];
+            }
+        }
+    }
+    if constexpr (LOOKAHEAD) {
         __syncthreads();
         for (uint32_t c = tid; c < kLaDummy; c += THREADS) {
             const uint32_t v = la[c];

@@ -15,5 +15,5 @@ import json
 for l in open("$OUT"):
     d=json.loads(l)
     if 'failed' in d: print(d); continue
-    print("%-62s %9.1f Mkeys/s  %7.3f ms  reorder %.3f ms %5.1f%%  histo %.3f ms" % (d['config']['workload'], d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'], 100*d['roofline']['frac'], d['phases_ms_per_launch']['histogram']))
+    print("%-62s %9.1f Mkeys/s  %7.3f ms  reorder %.3f ms %5.1f%%  histo %.3f scan %.4f paste %.4f" % (d["config"]["workload"], d["value"], d["ms_per_step"], d["roofline"]["avg_launch_ms"], 100*d["roofline"]["frac"], d["phases_ms_per_launch"]["histogram"], d["phases_ms_per_launch"]["scan"], d["phases_ms_per_launch"]["paste"]))
 PY
