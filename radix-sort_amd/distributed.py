@@ -72,7 +72,7 @@ def plan_exchange(bucket_offsets: list[int], rank: int, world_size: int, dist, d
     import torch
 
     mine = send_splits(bucket_offsets, world_size)
-    if world_size == 1:
+    if world_size == 1 and dist is None:
         return ExchangePlan(send=mine, recv=mine)
     t = torch.tensor(mine, dtype=torch.int64, device=device)
     gathered = torch.empty(world_size * world_size, dtype=torch.int64, device=device)
@@ -84,12 +84,15 @@ def plan_exchange(bucket_offsets: list[int], rank: int, world_size: int, dist, d
 class ShardedSorter:
     """Per-rank driver.  Buffers are torch tensors (device memory + RCCL plumbing)."""
 
-    def __init__(self, engine, rank: int, world_size: int, key_bits: int, dist=None):
+    def __init__(self, engine, rank: int, world_size: int, key_bits: int, dist=None, force_exchange: bool = False):
         self.engine = engine
         self.rank = rank
         self.world = world_size
         self.key_bits = key_bits
         self.dist = dist
+        # force_exchange: run partition -> all_gather -> all_to_all even with one rank (the
+        # collectives then talk to self); lets a 1-GPU box exercise the real RCCL call path
+        self.force_exchange = force_exchange and dist is not None
         if world_size > 1 and dist is None:
             raise ValueError("a torch.distributed module is required for world_size > 1")
 
@@ -99,7 +102,7 @@ class ShardedSorter:
         incoming keys.  Returns the number of keys this rank ends up with; the sorted
         keys stay inside the engine (engine.copy_result / result_device)."""
         n = keys.numel()
-        if self.world == 1:
+        if self.world == 1 and not self.force_exchange:
             self.engine.sort_from(keys.data_ptr(), n, payload.data_ptr() if payload is not None else None)
             return n
         offs = self.engine.partition(

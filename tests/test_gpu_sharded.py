@@ -105,3 +105,22 @@ def test_world_size_one_is_plain_sort(rsx, oracle):
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
         assert ShardedSorter(eng, 0, 1, 32).sort(keys, None, None) == keys_np.size
         assert np.array_equal(eng.download(), np.sort(keys_np))
+
+
+def test_bench_through_rccl_single_rank():
+    """bench.py launched by torch.distributed.run with ONE rank and RSX_FORCE_EXCHANGE=1: the
+    whole multi-GPU step (rsx_partition, all_gather of bucket counts, all_to_all_single with
+    split sizes, local sort) runs through the real nccl/RCCL backend, talking to itself."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RSX_FORCE_EXCHANGE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--log2-keys", "22"]
+    proc = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-3000:]
+    line = json.loads([l for l in proc.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["config"]["verified"] is True and line["n_gpus"] == 1
+    assert "all_to_all" in line["config"]["parallelism"] and line["value"] > 0
