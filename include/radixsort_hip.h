@@ -132,6 +132,13 @@ int rsx_fill_pad(rsx_engine* e, uint64_t byte_offset);
 int rsx_download(rsx_engine* e, void* host_keys_out, uint32_t* host_perm_out,
                  uint32_t* hist_out, uint64_t hist_cap, uint32_t* globsum_out, uint64_t globsum_cap);
 
+/* Pinned host memory for the transfers (the reference leaves a "consider CL_MEM_USE_HOST_PTR" note at
+ * src/ComputeDeviceData.cpp:26; pageable memcpy is what its avgTotalGPU column pays for).  rsx_pin_host
+ * page-locks a caller-owned range so that rsx_upload / rsx_download DMA straight from / to it;
+ * rsx_unpin_host undoes it.  Both are optional; unpinned buffers keep working. */
+int rsx_pin_host(rsx_engine* e, void* host_ptr, uint64_t bytes);
+int rsx_unpin_host(rsx_engine* e, void* host_ptr);
+
 /* ---- the hot path, step by step ---------------------------------------------
  * Asynchronous on the engine's stream; no host synchronisation inside.
  * rsx_histogram = RadixSortGPU::Histogram        (src/RadixSortGPU.cpp:16-61)

@@ -36,7 +36,7 @@ OPT_PROFILE, OPT_XCD_REMAP, OPT_FIRST_PASS, OPT_LAST_PASS, OPT_LOOKAHEAD = 0, 1,
 SYMBOLS = [
     "rsx_device_count", "rsx_device_name", "rsx_last_error", "rsx_version",
     "rsx_create", "rsx_destroy", "rsx_set_stream", "rsx_set_option", "rsx_get_geometry", "rsx_resize",
-    "rsx_upload", "rsx_fill_pad", "rsx_download",
+    "rsx_upload", "rsx_fill_pad", "rsx_download", "rsx_pin_host", "rsx_unpin_host",
     "rsx_histogram", "rsx_scan", "rsx_paste", "rsx_reorder", "rsx_sort", "rsx_sync",
     "rsx_sort_from", "rsx_partition", "rsx_result_device", "rsx_copy_result", "rsx_timings",
 ]
@@ -116,6 +116,8 @@ def load_library() -> C.CDLL:
         "rsx_upload": ([P, P, P, U64], I),
         "rsx_fill_pad": ([P, U64], I),
         "rsx_download": ([P, P, P, P, U64, P, U64], I),
+        "rsx_pin_host": ([P, P, U64], I),
+        "rsx_unpin_host": ([P, P], I),
         "rsx_histogram": ([P, I], I),
         "rsx_scan": ([P], I),
         "rsx_paste": ([P], I),
@@ -214,6 +216,12 @@ class Engine:
         k = np.ascontiguousarray(keys, dtype=self.dtype)
         p = None if perm is None else np.ascontiguousarray(perm, dtype=np.uint32)
         self._check(self.lib.rsx_upload(self._h, k.ctypes.data, p.ctypes.data if p is not None else None, k.size), "rsx_upload")
+
+    def pin_host(self, arr: np.ndarray) -> None:
+        self._check(self.lib.rsx_pin_host(self._h, arr.ctypes.data, arr.nbytes), "rsx_pin_host")
+
+    def unpin_host(self, arr: np.ndarray) -> None:
+        self._check(self.lib.rsx_unpin_host(self._h, arr.ctypes.data), "rsx_unpin_host")
 
     def fill_pad(self, byte_offset: int) -> None:
         self._check(self.lib.rsx_fill_pad(self._h, byte_offset), "rsx_fill_pad")

@@ -646,6 +646,22 @@ int rsx_download(rsx_engine* e, void* host_keys_out, uint32_t* host_perm_out, ui
     return RSX_OK;
 }
 
+int rsx_pin_host(rsx_engine* e, void* host_ptr, uint64_t bytes)
+{
+    if (!e || !host_ptr || bytes == 0) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_pin_host: null argument");
+    if (bind_device(e, RSX_HOST_BUFFERS_FAILED) != RSX_OK) return RSX_HOST_BUFFERS_FAILED;
+    RSX_TRY(hipHostRegister(host_ptr, static_cast<size_t>(bytes), hipHostRegisterDefault), RSX_HOST_BUFFERS_FAILED);
+    return RSX_OK;
+}
+
+int rsx_unpin_host(rsx_engine* e, void* host_ptr)
+{
+    if (!e || !host_ptr) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_unpin_host: null argument");
+    if (bind_device(e, RSX_HOST_BUFFERS_FAILED) != RSX_OK) return RSX_HOST_BUFFERS_FAILED;
+    RSX_TRY(hipHostUnregister(host_ptr), RSX_HOST_BUFFERS_FAILED);
+    return RSX_OK;
+}
+
 int rsx_histogram(rsx_engine* e, int pass)
 {
     if (!e) return fail(RSX_CALCULATION_FAILED, "rsx_histogram: null engine");

@@ -93,6 +93,7 @@ bool CRadixSortTask<T>::InitResources(hipc::Device Device, hipc::Context Context
     };
     mRadixSortGPU.enablePermutation(mOptions.with_permutation);
     mRadixSortGPU.setStepwise(mOptions.stepwise);
+    mRadixSortGPU.enablePinnedTransfers(mOptions.pinned);
     const auto status = mRadixSortGPU.initialize(Device, Context, mNumberKeys, spans);
     if (status != OperationStatus::OK) {
         std::cerr << "Failed to initialize Radix Sort on GPU: " << to_string(status) << " (" << static_cast<int>(status) << ")\n";

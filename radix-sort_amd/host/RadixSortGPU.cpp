@@ -59,6 +59,18 @@ OperationStatus RadixSortGPU<DataType>::initialize(hipc::Device Device, hipc::Co
     }
     rsx_resize(mEngine, mNumberKeysRounded);
     rsx_set_option(mEngine, RSX_OPT_PROFILE, 1);   // RuntimesGPU is always filled, as in the reference
+    mPinned = false;
+    if (mPinHost) {
+        const std::uint64_t keyBytes = static_cast<std::uint64_t>(mNumberKeysRounded) * sizeof(DataType);
+        bool ok = rsx_pin_host(mEngine, mHostSpans.m_hKeys.data(), keyBytes) == RSX_OK;
+        ok = ok && rsx_pin_host(mEngine, mHostSpans.m_hResultFromGPU.data(), keyBytes) == RSX_OK;
+        if (ok && mWithPermutation) ok = rsx_pin_host(mEngine, mHostSpans.h_Permut.data(), static_cast<std::uint64_t>(mNumberKeysRounded) * 4U) == RSX_OK;
+        if (!ok) {
+            release();
+            return S::HOST_BUFFERS_FAILED;
+        }
+        mPinned = true;
+    }
     mRuntimesGPU = RuntimesGPU{};
     mBoundStream = nullptr;
     return S::OK;
@@ -68,6 +80,12 @@ template <typename DataType>
 OperationStatus RadixSortGPU<DataType>::release()
 {
     if (!mEngine) return OperationStatus::OK;
+    if (mPinned) {
+        rsx_unpin_host(mEngine, mHostSpans.m_hKeys.data());
+        rsx_unpin_host(mEngine, mHostSpans.m_hResultFromGPU.data());
+        if (mWithPermutation) rsx_unpin_host(mEngine, mHostSpans.h_Permut.data());
+        mPinned = false;
+    }
     const int rc = rsx_destroy(mEngine);
     mEngine = nullptr;
     return static_cast<OperationStatus>(rc);

@@ -58,6 +58,10 @@ public:
     /// Call before initialize().
     void enablePermutation(bool on) noexcept { mWithPermutation = on; }
     void setStepwise(bool on) noexcept { mStepwise = on; }
+    /// Page-lock the key / result (and permutation) spans for the engine's lifetime so that
+    /// uploadData / downloadData DMA directly (the CL_MEM_USE_HOST_PTR idea the reference notes
+    /// at src/ComputeDeviceData.cpp:26).  Call before initialize().
+    void enablePinnedTransfers(bool on) noexcept { mPinHost = on; }
     std::uint32_t numberKeysRounded() const noexcept { return mNumberKeysRounded; }
 
 private:
@@ -79,5 +83,7 @@ private:
     void* mBoundStream{nullptr};
     bool mWithPermutation{false};
     bool mStepwise{false};
+    bool mPinHost{false};
+    bool mPinned{false};
     int mLastStatus{RSX_OK};
 };

@@ -23,6 +23,7 @@ struct RadixSortOptions {
     bool with_permutation{false};   ///< --with-permutation: carry h_Permut through the sort (argsort)
     bool stepwise{false};           ///< --stepwise: sync + host-time every launch like the reference
     bool skip_cpu{false};           ///< --skip-cpu: no CPU referees (large sizes); validation uses sortedness
+    bool pinned{false};             ///< --pinned: page-lock the host key/result buffers for the transfers
 
     explicit RadixSortOptions(std::vector<std::string> args = {})
         : num_elements(AlgorithmParameters<float>::_NUM_MAX_INPUT_ELEMS)   // default 2^25 (src/RadixSortOptions.h:18)
@@ -46,6 +47,8 @@ struct RadixSortOptions {
                 stepwise = true;
             } else if (arg == "--skip-cpu") {
                 skip_cpu = true;
+            } else if (arg == "--pinned") {
+                pinned = true;
             }
         }
     }
