@@ -50,3 +50,17 @@ def test_basic_sort_example():
     assert "Result: PASSED" in proc.stdout
     proc = _run([os.path.join(BIN, "basic_sort"), "1000003"])
     assert proc.returncode == 0 and "Result: PASSED" in proc.stdout
+
+
+def test_pinned_transfers_and_sweep_csv(tmp_path):
+    """--pinned page-locks the host spans (rsx_pin_host); the sweep script folds per-run CSVs
+    into one file with the reference's column order (Performance/performance.csv:1)."""
+    proc = _run([os.path.join(BIN, "rsx_tests"), "--num-elements", "300000", "--pinned", "--perf-to-stdout"])
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-2000:]
+    assert "20/20 task runs validated" in proc.stdout
+    out = tmp_path / "perf.csv"
+    proc = _run(["bash", os.path.join(ROOT, "tools", "performance_sweep.sh"), "12", "10", str(out)])
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = out.read_text().strip().splitlines()
+    assert lines[0].startswith("NumElements,Datatype,Dataset,avgHistogram,avgScan,avgPaste,avgReorder,avgTotalGPU,avgTotalSTLCPU,avgTotalRDXCPU")
+    assert len(lines) == 1 + 3 * 20 and lines[1].startswith("4096,uint32_t,Zeros,")
