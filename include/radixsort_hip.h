@@ -81,12 +81,12 @@ typedef struct rsx_geometry {
     uint32_t tile_threads;     /* workgroup size of histogram/reorder */
     uint32_t keys_per_thread;
     uint32_t tile_keys;        /* keys per tile = table column */
-    uint32_t scan_block;       /* table entries per scan workgroup */
+    uint32_t scan_block;       /* tiles per scan group: a group = this many consecutive tiles of ONE digit */
     uint64_t num_keys;         /* active length (rsx_resize / rsx_upload) */
     uint64_t capacity;
     uint64_t num_tiles;        /* ceil(num_keys / tile_keys) */
     uint64_t table_len;        /* RSX_RADIX * num_tiles, layout [digit][tile] */
-    uint64_t num_scan_blocks;  /* ceil(table_len / scan_block) = live entries of globsum */
+    uint64_t num_scan_blocks;  /* 16 * ceil(num_tiles / scan_block) = live entries of globsum, layout [digit][group] */
     uint32_t num_passes;       /* key bits / 4 */
     uint32_t key_bytes;
 } rsx_geometry;

@@ -211,25 +211,25 @@ int launch_scan(rsx_engine* e, uint64_t count, bool from_counts = false)
 {
     if (count == 0) return RSX_OK;
     const uint32_t ntiles = static_cast<uint32_t>(e->ntiles(count));
-    const uint64_t len = static_cast<uint64_t>(RSX_RADIX) * ntiles;
-    const uint32_t nblocks = static_cast<uint32_t>((len + rsx::kScanBlock - 1) / rsx::kScanBlock);
+    const uint32_t ngroups = (ntiles + rsx::kScanTiles - 1) / rsx::kScanTiles;
     {
         Bracket b(e, PH_SCAN);
         if (from_counts && e->scan_zeroes) {
-            hipLaunchKernelGGL((rsx::scan_blocks_kernel<true, true>), dim3(nblocks), dim3(rsx::kScanThreads), 0, e->stream, e->table, e->globsum,
-                               len, e->counts_next, ntiles);
+            hipLaunchKernelGGL((rsx::scan_blocks_kernel<true, true>), dim3(ngroups), dim3(rsx::kScanTiles), 0, e->stream, e->table, e->globsum,
+                               ntiles, ngroups, e->counts_next);
         } else if (from_counts) {
-            hipLaunchKernelGGL((rsx::scan_blocks_kernel<true, false>), dim3(nblocks), dim3(rsx::kScanThreads), 0, e->stream, e->table, e->globsum,
-                               len, e->counts_next, ntiles);
+            hipLaunchKernelGGL((rsx::scan_blocks_kernel<true, false>), dim3(ngroups), dim3(rsx::kScanTiles), 0, e->stream, e->table, e->globsum,
+                               ntiles, ngroups, e->counts_next);
         } else {
-            hipLaunchKernelGGL((rsx::scan_blocks_kernel<false, false>), dim3(nblocks), dim3(rsx::kScanThreads), 0, e->stream, e->table, e->globsum,
-                               len, static_cast<uint32_t*>(nullptr), ntiles);
+            hipLaunchKernelGGL((rsx::scan_blocks_kernel<false, false>), dim3(ngroups), dim3(rsx::kScanTiles), 0, e->stream, e->table, e->globsum,
+                               ntiles, ngroups, static_cast<uint32_t*>(nullptr));
         }
     }
     RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
     {
         Bracket b(e, PH_SCAN);
-        hipLaunchKernelGGL(rsx::scan_globsum_kernel, dim3(1), dim3(rsx::kGlobsumThreads), 0, e->stream, e->globsum, e->temp, nblocks);
+        hipLaunchKernelGGL(rsx::scan_globsum_kernel, dim3(1), dim3(rsx::kGlobsumThreads), 0, e->stream, e->globsum, e->temp,
+                           static_cast<uint32_t>(RSX_RADIX) * ngroups);
     }
     RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
     return RSX_OK;
@@ -238,10 +238,10 @@ int launch_scan(rsx_engine* e, uint64_t count, bool from_counts = false)
 int launch_paste(rsx_engine* e, uint64_t count)
 {
     if (count == 0) return RSX_OK;
-    const uint64_t len = static_cast<uint64_t>(RSX_RADIX) * e->ntiles(count);
-    const uint32_t nblocks = static_cast<uint32_t>((len + rsx::kScanBlock - 1) / rsx::kScanBlock);
+    const uint32_t ntiles = static_cast<uint32_t>(e->ntiles(count));
+    const uint32_t ngroups = (ntiles + rsx::kScanTiles - 1) / rsx::kScanTiles;
     Bracket b(e, PH_PASTE);
-    hipLaunchKernelGGL(rsx::paste_kernel, dim3(nblocks), dim3(rsx::kScanThreads), 0, e->stream, e->table, e->globsum, len);
+    hipLaunchKernelGGL(rsx::paste_kernel, dim3(ngroups), dim3(rsx::kScanTiles), 0, e->stream, e->table, e->globsum, ntiles, ngroups);
     RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
     return RSX_OK;
 }
@@ -450,11 +450,11 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
         }
     }
     e->table_cap = static_cast<uint64_t>(RSX_RADIX) * e->ntiles(capacity);
-    if ((e->table_cap + rsx::kScanBlock - 1) / rsx::kScanBlock > rsx::kMaxScanBlocks) {
+    if ((e->ntiles(capacity) + rsx::kScanTiles - 1) / rsx::kScanTiles > rsx::kMaxScanGroups) {
         return bail(RSX_RESIZE_FAILED, "rsx_create: capacity exceeds the two-level table scan", hipSuccess);
     }
-    // table rounded up to whole scan blocks so vector accesses of the tail stay in bounds
-    const size_t table_alloc = ((e->table_cap + rsx::kScanBlock - 1) / rsx::kScanBlock) * rsx::kScanBlock * 4;
+    // rounded up to whole scan groups (keeps 16-byte row accesses of the last group in bounds)
+    const size_t table_alloc = ((e->ntiles(capacity) + rsx::kScanTiles - 1) / rsx::kScanTiles) * rsx::kScanTiles * RSX_RADIX * 4;
     if ((err = hipMalloc(reinterpret_cast<void**>(&e->table), table_alloc)) != hipSuccess)
         return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(histograms)", err);
     if ((err = hipMalloc(reinterpret_cast<void**>(&e->counts_next), table_alloc)) != hipSuccess)
@@ -559,7 +559,7 @@ int rsx_get_geometry(const rsx_engine* e, rsx_geometry* out)
     out->capacity = e->capacity;
     out->num_tiles = e->ntiles(e->n);
     out->table_len = static_cast<uint64_t>(RSX_RADIX) * out->num_tiles;
-    out->num_scan_blocks = (out->table_len + rsx::kScanBlock - 1) / rsx::kScanBlock;
+    out->num_scan_blocks = static_cast<uint64_t>(RSX_RADIX) * ((out->num_tiles + rsx::kScanTiles - 1) / rsx::kScanTiles);
     out->num_passes = e->passes();
     out->key_bytes = static_cast<uint32_t>(e->key_bytes);
     return RSX_OK;

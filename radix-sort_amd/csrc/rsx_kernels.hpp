@@ -193,116 +193,108 @@ __global__ __launch_bounds__(THREADS) void histogram_kernel(const Key* __restric
 }
 
 // ---------------------------------------------------------------------------
-// scan of the flattened [digit][tile] table (ScanHistogram / PasteHistogram)
+// scan of the [digit][tile] table (ScanHistogram / PasteHistogram)
 // ---------------------------------------------------------------------------
-constexpr int kScanThreads = 256;
-constexpr int kScanPerThread = 16;
-constexpr int kScanBlock = kScanThreads * kScanPerThread;     // 4096 table entries per workgroup
+// Two levels like the reference (512 groups of 32 entries -> scan of the group sums -> paste,
+// RadixSort.cl:125-197), cut differently: a scan group is 256 consecutive TILES of all 16
+// digits (4096 entries), so the raw counts are read as whole [tile][16] rows when they come
+// from the look-ahead buffer and as 16 coalesced row segments when they come from the
+// histogram kernel.  Group sums live in globsum[digit][group]; their exclusive scan in that
+// (digit-major) order is the global offset of each group.
+constexpr int kScanTiles = 256;                               // tiles per scan group = threads per workgroup
+constexpr int kScanBlock = kScanTiles;                        // entries of ONE digit per scan group
 constexpr int kGlobsumThreads = 1024;
-constexpr int kGlobsumPerThread = 4;
-constexpr int kMaxScanBlocks = kGlobsumThreads * kGlobsumPerThread;   // 4096 block sums
+constexpr int kMaxScanGroups = 4096;                          // 2^20 tiles
+constexpr int kMaxScanBlocks = kRadix * kMaxScanGroups;       // entries of globsum
 
-// scan #1: exclusive scan inside every block of 4096 entries, block total -> globsum[block].
-// FROM_COUNTS: the raw counts come from the look-ahead buffer in [tile][digit] layout and
-// are gathered into the digit-major order of the table on the fly.
+// scan #1: exclusive scan over the 256 tiles of the group, per digit; group total -> globsum[d][group]
 template <bool FROM_COUNTS, bool ZERO_BACK = true>
-__global__ __launch_bounds__(kScanThreads) void scan_blocks_kernel(uint32_t* __restrict__ table, uint32_t* __restrict__ globsum,
-                                                                    uint64_t len, uint32_t* __restrict__ counts, uint32_t ntiles)
+__global__ __launch_bounds__(kScanTiles) void scan_blocks_kernel(uint32_t* __restrict__ table, uint32_t* __restrict__ globsum,
+                                                                  uint32_t ntiles, uint32_t ngroups, uint32_t* __restrict__ counts)
 {
-    __shared__ uint32_t wtot[kScanThreads / kWave];
-    const uint32_t tid = threadIdx.x;
-    const uint64_t first = static_cast<uint64_t>(blockIdx.x) * kScanBlock + static_cast<uint64_t>(tid) * kScanPerThread;
-    uint32_t v[kScanPerThread];
+    constexpr int WAVES = kScanTiles / kWave;
+    __shared__ uint32_t wsum[WAVES][kRadix];
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    const uint32_t group = blockIdx.x;
+    const uint32_t tile = group * kScanTiles + tid;
+    const bool live = tile < ntiles;
+    uint32_t c[kRadix];
     if constexpr (FROM_COUNTS) {
-        uint32_t d = static_cast<uint32_t>(first / ntiles);
-        uint32_t t = static_cast<uint32_t>(first - static_cast<uint64_t>(d) * ntiles);
+        // one [tile][16] row per thread: 64 contiguous bytes; handed back zeroed so that the next
+        // look-ahead pass needs no memset
+        U32x4* row = reinterpret_cast<U32x4*>(counts + static_cast<uint64_t>(tile) * kRadix);
 #pragma unroll
-        for (int i = 0; i < kScanPerThread; ++i) {
-            if (first + i < len) {
-                // every counter is read by exactly one thread: hand it back zeroed, so the next
-                // look-ahead pass needs no memset
-                uint32_t* c = counts + static_cast<uint64_t>(t) * kRadix + d;
-                v[i] = *c;
+        for (int q = 0; q < 4; ++q) {
+            U32x4 x = {{0u, 0u, 0u, 0u}};
+            if (live) {
+                x = row[q];
                 if constexpr (ZERO_BACK) {
-                    *c = 0u;
+                    row[q] = U32x4{{0u, 0u, 0u, 0u}};
                 }
-            } else {
-                v[i] = 0u;
             }
-            if (++t == ntiles) {
-                t = 0;
-                ++d;
-            }
-        }
-    } else if (first + kScanPerThread <= len) {
-#pragma unroll
-        for (int q = 0; q < kScanPerThread / 4; ++q) {
-            const U32x4 x = *reinterpret_cast<const U32x4*>(table + first + q * 4);
-            v[q * 4 + 0] = x.v[0];
-            v[q * 4 + 1] = x.v[1];
-            v[q * 4 + 2] = x.v[2];
-            v[q * 4 + 3] = x.v[3];
+            c[q * 4 + 0] = x.v[0];
+            c[q * 4 + 1] = x.v[1];
+            c[q * 4 + 2] = x.v[2];
+            c[q * 4 + 3] = x.v[3];
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < kScanPerThread; ++i) {
-            v[i] = (first + i < len) ? table[first + i] : 0u;
+        for (int d = 0; d < kRadix; ++d) {
+            c[d] = live ? table[static_cast<uint64_t>(d) * ntiles + tile] : 0u;
         }
     }
-    uint32_t sum = 0;
+    uint32_t incl[kRadix];
 #pragma unroll
-    for (int i = 0; i < kScanPerThread; ++i) {
-        const uint32_t c = v[i];
-        v[i] = sum;
-        sum += c;
+    for (int d = 0; d < kRadix; ++d) {
+        incl[d] = wave_inclusive_scan(c[d]);
     }
-    uint32_t total;
-    const uint32_t before = block_exclusive_scan<kScanThreads>(sum, wtot, total);
-    if (first + kScanPerThread <= len) {
+    if (lane == kWave - 1) {
 #pragma unroll
-        for (int q = 0; q < kScanPerThread / 4; ++q) {
-            U32x4 x;
-            x.v[0] = v[q * 4 + 0] + before;
-            x.v[1] = v[q * 4 + 1] + before;
-            x.v[2] = v[q * 4 + 2] + before;
-            x.v[3] = v[q * 4 + 3] + before;
-            *reinterpret_cast<U32x4*>(table + first + q * 4) = x;
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < kScanPerThread; ++i) {
-            if (first + i < len) {
-                table[first + i] = v[i] + before;
-            }
+        for (int d = 0; d < kRadix; ++d) {
+            wsum[wave][d] = incl[d];
         }
     }
-    if (tid == 0) {
-        globsum[blockIdx.x] = total;
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < kRadix; ++d) {
+        uint32_t before = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            before += (static_cast<uint32_t>(w) < wave) ? wsum[w][d] : 0u;
+        }
+        if (live) {
+            table[static_cast<uint64_t>(d) * ntiles + tile] = before + incl[d] - c[d];
+        }
+    }
+    if (tid < kRadix) {
+        uint32_t total = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            total += wsum[w][tid];
+        }
+        globsum[static_cast<uint64_t>(tid) * ngroups + group] = total;
     }
 }
 
-// scan #2: exclusive scan of the block sums in place, grand total -> temp[0]
+// scan #2: exclusive scan of the group sums in place (digit-major), grand total -> temp[0]
 __global__ __launch_bounds__(kGlobsumThreads) void scan_globsum_kernel(uint32_t* __restrict__ globsum, uint32_t* __restrict__ temp,
-                                                                        uint32_t nblocks)
+                                                                        uint32_t nentries)
 {
     __shared__ uint32_t wtot[kGlobsumThreads / kWave];
     const uint32_t tid = threadIdx.x;
-    uint32_t v[kGlobsumPerThread];
+    const uint32_t per = (nentries + kGlobsumThreads - 1) / kGlobsumThreads;     // <= 64
+    const uint32_t first = tid * per;
     uint32_t sum = 0;
-#pragma unroll
-    for (int i = 0; i < kGlobsumPerThread; ++i) {
-        const uint32_t idx = tid * kGlobsumPerThread + i;
-        const uint32_t c = idx < nblocks ? globsum[idx] : 0u;
-        v[i] = sum;
-        sum += c;
+    for (uint32_t i = 0; i < per; ++i) {
+        sum += (first + i < nentries) ? globsum[first + i] : 0u;
     }
     uint32_t total;
-    const uint32_t before = block_exclusive_scan<kGlobsumThreads>(sum, wtot, total);
-#pragma unroll
-    for (int i = 0; i < kGlobsumPerThread; ++i) {
-        const uint32_t idx = tid * kGlobsumPerThread + i;
-        if (idx < nblocks) {
-            globsum[idx] = v[i] + before;
+    uint32_t run = block_exclusive_scan<kGlobsumThreads>(sum, wtot, total);
+    for (uint32_t i = 0; i < per; ++i) {
+        if (first + i < nentries) {
+            const uint32_t cnt = globsum[first + i];
+            globsum[first + i] = run;
+            run += cnt;
         }
     }
     if (tid == 0) {
@@ -310,29 +302,18 @@ __global__ __launch_bounds__(kGlobsumThreads) void scan_globsum_kernel(uint32_t*
     }
 }
 
-// paste: every entry of block b += scanned globsum[b] -> table holds the global exclusive prefix
-__global__ __launch_bounds__(kScanThreads) void paste_kernel(uint32_t* __restrict__ table, const uint32_t* __restrict__ globsum,
-                                                              uint64_t len)
+// paste: every entry of (digit d, group g) += scanned globsum[d][g] -> global exclusive prefix
+__global__ __launch_bounds__(kScanTiles) void paste_kernel(uint32_t* __restrict__ table, const uint32_t* __restrict__ globsum,
+                                                            uint32_t ntiles, uint32_t ngroups)
 {
-    const uint32_t add = globsum[blockIdx.x];
-    const uint64_t first = static_cast<uint64_t>(blockIdx.x) * kScanBlock + static_cast<uint64_t>(threadIdx.x) * kScanPerThread;
-    if (first + kScanPerThread <= len) {
+    const uint32_t group = blockIdx.x;
+    const uint32_t tile = group * kScanTiles + threadIdx.x;
+    if (tile >= ntiles) {
+        return;
+    }
 #pragma unroll
-        for (int q = 0; q < kScanPerThread / 4; ++q) {
-            U32x4 x = *reinterpret_cast<const U32x4*>(table + first + q * 4);
-            x.v[0] += add;
-            x.v[1] += add;
-            x.v[2] += add;
-            x.v[3] += add;
-            *reinterpret_cast<U32x4*>(table + first + q * 4) = x;
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < kScanPerThread; ++i) {
-            if (first + i < len) {
-                table[first + i] += add;
-            }
-        }
+    for (int d = 0; d < kRadix; ++d) {
+        table[static_cast<uint64_t>(d) * ntiles + tile] += globsum[static_cast<uint64_t>(d) * ngroups + group];
     }
 }
 
@@ -466,9 +447,10 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
         first_hi = table[e_hi];
         if (globsum) {
             // PasteHistogram folded in: the table holds block-local prefixes, add the scanned
-            // sum of the 4096-entry scan block each entry lives in (RadixSort.cl:185-197)
-            first_lo += globsum[e_lo / kScanBlock];
-            first_hi += globsum[e_hi / kScanBlock];
+            // sum of the scan group (256 tiles of one digit) each entry lives in (RadixSort.cl:185-197)
+            const uint32_t ngroups = (ntiles + kScanTiles - 1) / kScanTiles;
+            first_lo += globsum[static_cast<uint64_t>(hl) * ngroups + tile / kScanTiles];
+            first_hi += globsum[static_cast<uint64_t>(hl + 8) * ngroups + tile / kScanTiles];
         }
     }
 

@@ -147,17 +147,23 @@ def test_histogram_scan_paste_reorder_steps(mod, oracle, dt, n):
 
 
 def test_globsum_is_exclusive_scan_of_block_sums(mod, oracle):
-    n = 1 << 20
+    """Level 2 of the table scan: globsum[digit][group] (a group = scan_block consecutive tiles of
+    one digit) holds, after rsx_scan, the exclusive prefix of the group sums in digit-major order
+    (the reference's globsum after its second scanhistograms launch, RadixSortGPU.cpp:115-152)."""
+    n = (1 << 21) + 12345
     keys = oracle.dataset("Random", "uint32", n)
     with mod.Engine("uint32", n) as e:
         e.upload(keys)
         e.histogram(0)
-        _, counts = e.download(hist_cap=16 * e.geometry().num_tiles)
-        e.scan()
         g = e.geometry()
+        _, counts = e.download(hist_cap=16 * g.num_tiles)
+        e.scan()
         _, gs = e.download(globsum_cap=int(g.num_scan_blocks))
-        pad = (-counts.size) % g.scan_block
-        sums = np.concatenate([counts, np.zeros(pad, dtype=np.uint32)]).reshape(-1, g.scan_block).sum(axis=1)
+        ngroups = g.num_scan_blocks // 16
+        rows = counts.reshape(16, g.num_tiles).astype(np.uint64)
+        pad = ngroups * g.scan_block - g.num_tiles
+        rows = np.concatenate([rows, np.zeros((16, pad), dtype=np.uint64)], axis=1)
+        sums = rows.reshape(16, ngroups, g.scan_block).sum(axis=2).reshape(-1)
         assert np.array_equal(gs, np.concatenate([[0], np.cumsum(sums)[:-1]]).astype(np.uint32))
 
 
