@@ -164,6 +164,17 @@ int rsx_sync(rsx_engine* e);   /* CommandQueue.finish() */
 int rsx_sort_from(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n);
 int rsx_partition(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n,
                   int shift, int bits, void* d_keys_out, uint32_t* d_payload_out, uint64_t* bucket_offsets);
+/* Range-adaptive partition for the multi-GPU exchange (keys whose top bits are all equal — small
+ * ranges, sorted inputs — would otherwise land on one rank):
+ * rsx_key_range: min and max of n device-resident keys in unsigned sort order (key ^ sign bit),
+ *   returned as uint64; n == 0 gives lo = UINT64_MAX, hi = 0.  Synchronises.
+ * rsx_partition_range: like rsx_partition with x = (key ^ sign) - lo and
+ *   bucket = min(mul ? mulhi(x, mul) : x >> shift, 15), mul = floor(16 * 2^keybits / (hi - lo + 1)):
+ *   16 equal-width buckets over [lo, hi] (mul == 0 for ranges of at most 16 values);
+ *   bucket_offsets receives 17 entries. */
+int rsx_key_range(rsx_engine* e, const void* d_keys, uint64_t n, uint64_t* lo, uint64_t* hi);
+int rsx_partition_range(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n, uint64_t lo, int shift, uint64_t mul,
+                        void* d_keys_out, uint32_t* d_payload_out, uint64_t* bucket_offsets);
 int rsx_result_device(rsx_engine* e, void** d_keys, uint32_t** d_payload);
 int rsx_copy_result(rsx_engine* e, void* d_keys_out, uint32_t* d_payload_out);
 

@@ -104,6 +104,8 @@ struct rsx_engine {
     uint32_t* globsum = nullptr;                // block sums of the table scan
     uint32_t* temp = nullptr;                   // grand total of scan #2
     uint32_t* counts_next = nullptr;            // look-ahead histogram of the next pass, [tile][digit]
+    unsigned long long* range_dev = nullptr;    // per-workgroup {min, max} of rsx_key_range
+    unsigned long long* range_host = nullptr;   // pinned mirror
     uint32_t* starts_dev = nullptr;             // 16 bucket starts (rsx_partition)
     uint32_t* starts_host = nullptr;            // pinned mirror
     uint64_t table_cap = 0;
@@ -194,15 +196,15 @@ Grid grid_for(const rsx_engine* e, uint64_t count)
     return g;
 }
 
-template <typename Key>
-int launch_histogram(rsx_engine* e, const void* in, uint64_t count, int shift, uint32_t mask)
+template <typename Key, bool RANGED = false>
+int launch_histogram(rsx_engine* e, const void* in, uint64_t count, int shift, uint32_t mask, Key lo = Key{0}, Key mul = Key{0})
 {
     if (count == 0) return RSX_OK;
     const Grid g = grid_for(e, count);
     Bracket b(e, PH_HISTO);
-    hipLaunchKernelGGL((rsx::histogram_kernel<Key, kTileThreads, kKeysPerThread>), dim3(g.blocks), dim3(kTileThreads), 0, e->stream,
+    hipLaunchKernelGGL((rsx::histogram_kernel<Key, kTileThreads, kKeysPerThread, RANGED>), dim3(g.blocks), dim3(kTileThreads), 0, e->stream,
                        static_cast<const Key*>(in), e->table, count, g.ntiles, g.tiles_per_xcd, e->xcd_remap, shift,
-                       flip_mask<Key>(e), mask);
+                       flip_mask<Key>(e), mask, lo, mul);
     RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
     return RSX_OK;
 }
@@ -250,17 +252,17 @@ int launch_paste(rsx_engine* e, uint64_t count)
 // OUTPUT tile into e->counts_next (all zero on entry: zeroed at the start of the sort and handed
 // back zeroed by the scan that consumes it).  fold_paste: the table holds block-local prefixes
 // and the kernel adds the scanned block sums itself (no paste launch).
-template <typename Key, bool PAYLOAD, bool LOOKAHEAD>
+template <typename Key, bool PAYLOAD, bool LOOKAHEAD, bool RANGED = false>
 int launch_reorder_t(rsx_engine* e, const void* in, void* out, const uint32_t* pin, uint32_t* pout, uint64_t count, int shift,
-                     uint32_t mask, int next_shift, bool fold_paste)
+                     uint32_t mask, int next_shift, bool fold_paste, Key lo = Key{0}, Key mul = Key{0})
 {
     using L = rsx::ReorderLayout<Key, kTileThreads, kKeysPerThread>;
     const Grid g = grid_for(e, count);
     Bracket b(e, PH_REORDER);
-    hipLaunchKernelGGL((rsx::reorder_kernel<Key, kTileThreads, kKeysPerThread, PAYLOAD, LOOKAHEAD>), dim3(g.blocks), dim3(kTileThreads),
+    hipLaunchKernelGGL((rsx::reorder_kernel<Key, kTileThreads, kKeysPerThread, PAYLOAD, LOOKAHEAD, RANGED>), dim3(g.blocks), dim3(kTileThreads),
                        L::BYTES, e->stream, static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->table, count,
                        g.ntiles, g.tiles_per_xcd, e->xcd_remap, shift, flip_mask<Key>(e), mask, e->counts_next, next_shift,
-                       fold_paste ? static_cast<const uint32_t*>(e->globsum) : static_cast<const uint32_t*>(nullptr));
+                       fold_paste ? static_cast<const uint32_t*>(e->globsum) : static_cast<const uint32_t*>(nullptr), lo, mul);
     RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
     return RSX_OK;
 }
@@ -279,11 +281,11 @@ int launch_reorder(rsx_engine* e, const void* in, void* out, const uint32_t* pin
                    : launch_reorder_t<Key, false, false>(e, in, out, nullptr, nullptr, count, shift, mask, 0, fold_paste);
 }
 
-template <typename Key, bool PAYLOAD, bool LOOKAHEAD>
+template <typename Key, bool PAYLOAD, bool LOOKAHEAD, bool RANGED = false>
 int allow_lds()
 {
     using L = rsx::ReorderLayout<Key, kTileThreads, kKeysPerThread>;
-    RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder_kernel<Key, kTileThreads, kKeysPerThread, PAYLOAD, LOOKAHEAD>),
+    RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder_kernel<Key, kTileThreads, kKeysPerThread, PAYLOAD, LOOKAHEAD, RANGED>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L::BYTES)),
             RSX_INITIALIZATION_FAILED);
     return RSX_OK;
@@ -298,6 +300,41 @@ int run_pass(rsx_engine* e, const void* in, void* out, const uint32_t* pin, uint
     if ((rc = launch_scan(e, count)) != RSX_OK) return rc;
     if ((rc = launch_paste(e, count)) != RSX_OK) return rc;
     return launch_reorder<Key>(e, in, out, pin, pout, count, shift, mask);
+}
+
+// One stable pass with the ranged bucket function (multi-GPU partition).
+template <typename Key>
+int run_ranged_pass(rsx_engine* e, const void* in, void* out, const uint32_t* pin, uint32_t* pout, uint64_t count, uint64_t lo, int shift,
+                    uint64_t mul)
+{
+    const Key klo = static_cast<Key>(lo), kmul = static_cast<Key>(mul);
+    int rc;
+    if ((rc = launch_histogram<Key, true>(e, in, count, shift, RSX_RADIX - 1, klo, kmul)) != RSX_OK) return rc;
+    if ((rc = launch_scan(e, count)) != RSX_OK) return rc;
+    if ((rc = launch_paste(e, count)) != RSX_OK) return rc;
+    if (pin && pout) return launch_reorder_t<Key, true, false, true>(e, in, out, pin, pout, count, shift, RSX_RADIX - 1, 0, false, klo, kmul);
+    return launch_reorder_t<Key, false, false, true>(e, in, out, nullptr, nullptr, count, shift, RSX_RADIX - 1, 0, false, klo, kmul);
+}
+
+constexpr int kRangeBlocks = 2048;
+
+template <typename Key>
+int key_range(rsx_engine* e, const void* d_keys, uint64_t n, uint64_t* lo, uint64_t* hi)
+{
+    const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>(kRangeBlocks, (n + 4095) / 4096));
+    hipLaunchKernelGGL(rsx::key_range_kernel<Key>, dim3(blocks), dim3(rsx::kRangeThreads), 0, e->stream, static_cast<const Key*>(d_keys), n,
+                       flip_mask<Key>(e), e->range_dev);
+    RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
+    RSX_TRY(hipMemcpyAsync(e->range_host, e->range_dev, static_cast<size_t>(blocks) * 16, hipMemcpyDeviceToHost, e->stream), RSX_CALCULATION_FAILED);
+    RSX_TRY(hipStreamSynchronize(e->stream), RSX_CALCULATION_FAILED);
+    unsigned long long l = ~0ull, h = 0ull;
+    for (uint32_t b = 0; b < blocks; ++b) {
+        l = std::min(l, e->range_host[2 * b]);
+        h = std::max(h, e->range_host[2 * b + 1]);
+    }
+    *lo = l;
+    *hi = h;
+    return RSX_OK;
 }
 
 template <typename Key>
@@ -463,6 +500,10 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
         return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(globsum)", err);
     if ((err = hipMalloc(reinterpret_cast<void**>(&e->temp), 64)) != hipSuccess)
         return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(temp)", err);
+    if ((err = hipMalloc(reinterpret_cast<void**>(&e->range_dev), kRangeBlocks * 16)) != hipSuccess)
+        return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(range)", err);
+    if ((err = hipHostMalloc(reinterpret_cast<void**>(&e->range_host), kRangeBlocks * 16, hipHostMallocDefault)) != hipSuccess)
+        return bail(RSX_HOST_BUFFERS_FAILED, "hipHostMalloc(range)", err);
     if ((err = hipMalloc(reinterpret_cast<void**>(&e->starts_dev), RSX_RADIX * 4)) != hipSuccess)
         return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(starts)", err);
     if ((err = hipHostMalloc(reinterpret_cast<void**>(&e->starts_host), RSX_RADIX * 4, hipHostMallocDefault)) != hipSuccess)
@@ -479,6 +520,10 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
     if (rc == RSX_OK) rc = allow_lds<uint32_t, true, true>();
     if (rc == RSX_OK) rc = allow_lds<uint64_t, false, true>();
     if (rc == RSX_OK) rc = allow_lds<uint64_t, true, true>();
+    if (rc == RSX_OK) rc = allow_lds<uint32_t, false, false, true>();
+    if (rc == RSX_OK) rc = allow_lds<uint32_t, true, false, true>();
+    if (rc == RSX_OK) rc = allow_lds<uint64_t, false, false, true>();
+    if (rc == RSX_OK) rc = allow_lds<uint64_t, true, false, true>();
     if (rc != RSX_OK) {
         rsx_destroy(e);
         return rc;
@@ -509,6 +554,8 @@ int rsx_destroy(rsx_engine* e)
     if (e->globsum && hipFree(e->globsum) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->temp && hipFree(e->temp) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->starts_dev && hipFree(e->starts_dev) != hipSuccess) status = RSX_CLEANUP_FAILED;
+    if (e->range_dev && hipFree(e->range_dev) != hipSuccess) status = RSX_CLEANUP_FAILED;
+    if (e->range_host && hipHostFree(e->range_host) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->starts_host && hipHostFree(e->starts_host) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->own_stream && e->stream && hipStreamDestroy(e->stream) != hipSuccess) status = RSX_CLEANUP_FAILED;
     delete e;
@@ -760,6 +807,47 @@ int rsx_partition(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, 
     RSX_TRY(hipStreamSynchronize(e->stream), RSX_CALCULATION_FAILED);
     for (uint32_t d = 0; d < buckets; ++d) bucket_offsets[d] = e->starts_host[d];
     bucket_offsets[buckets] = n;
+    return RSX_OK;
+}
+
+int rsx_key_range(rsx_engine* e, const void* d_keys, uint64_t n, uint64_t* lo, uint64_t* hi)
+{
+    if (!e || !lo || !hi) return fail(RSX_CALCULATION_FAILED, "rsx_key_range: null argument");
+    *lo = ~0ull;
+    *hi = 0ull;
+    if (n == 0) return RSX_OK;
+    if (!d_keys || !aligned16(d_keys)) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_key_range: keys must be a 16-byte aligned device pointer");
+    if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
+    return RSX_BY_KEY(e, key_range<uint32_t>(e, d_keys, n, lo, hi), key_range<uint64_t>(e, d_keys, n, lo, hi));
+}
+
+int rsx_partition_range(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n, uint64_t lo, int shift, uint64_t mul,
+                        void* d_keys_out, uint32_t* d_payload_out, uint64_t* bucket_offsets)
+{
+    if (!e || !bucket_offsets) return fail(RSX_CALCULATION_FAILED, "rsx_partition_range: null argument");
+    if (shift < 0 || shift >= e->key_bytes * 8) return fail(RSX_CALCULATION_FAILED, "rsx_partition_range: shift out of range");
+    if (n > e->capacity) return fail(RSX_RESIZE_FAILED, "rsx_partition_range: beyond capacity");
+    if (n > 0 && (!d_keys || !d_keys_out || !aligned16(d_keys) || !aligned16(d_keys_out)))
+        return fail(RSX_HOST_BUFFERS_FAILED, "rsx_partition_range: key buffers must be 16-byte aligned device pointers");
+    const bool with_payload = e->has_payload && d_payload && d_payload_out;
+    if (e->has_payload && !with_payload && n > 0) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_partition_range: payload engine needs payload buffers");
+    if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
+    if (n == 0) {
+        for (uint32_t d = 0; d <= RSX_RADIX; ++d) bucket_offsets[d] = 0;
+        return RSX_OK;
+    }
+    const uint32_t* pin = with_payload ? d_payload : nullptr;
+    uint32_t* pout = with_payload ? d_payload_out : nullptr;
+    if (e->key_bytes == 4 && mul > 0xFFFFFFFFull) return fail(RSX_CALCULATION_FAILED, "rsx_partition_range: multiplier exceeds the key width");
+    const int rc = RSX_BY_KEY(e, run_ranged_pass<uint32_t>(e, d_keys, d_keys_out, pin, pout, n, lo, shift, mul),
+                              run_ranged_pass<uint64_t>(e, d_keys, d_keys_out, pin, pout, n, lo, shift, mul));
+    if (rc != RSX_OK) return rc;
+    hipLaunchKernelGGL(rsx::bucket_starts_kernel, dim3(1), dim3(64), 0, e->stream, e->table, static_cast<uint32_t>(e->ntiles(n)), e->starts_dev);
+    RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
+    RSX_TRY(hipMemcpyAsync(e->starts_host, e->starts_dev, RSX_RADIX * 4, hipMemcpyDeviceToHost, e->stream), RSX_CALCULATION_FAILED);
+    RSX_TRY(hipStreamSynchronize(e->stream), RSX_CALCULATION_FAILED);
+    for (uint32_t d = 0; d < RSX_RADIX; ++d) bucket_offsets[d] = e->starts_host[d];
+    bucket_offsets[RSX_RADIX] = n;
     return RSX_OK;
 }
 

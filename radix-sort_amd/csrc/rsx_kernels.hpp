@@ -74,6 +74,21 @@ __device__ __forceinline__ uint32_t digit_of(Key key, int shift, Key flip, uint3
     return static_cast<uint32_t>((key ^ flip) >> shift) & mask;
 }
 
+// Bucket of the multi-GPU partition pass: x = (key ^ sign) - lo, 16 equal-width buckets over the
+// global key range.  mul != 0: floor(x * 16 / (hi - lo + 1)) as a multiply-high by
+// mul = floor(16 * 2^W / (hi - lo + 1)); mul == 0 (ranges of at most 16 values): x >> shift.
+// Monotone in the key either way; the clamp only ever catches the padding key.
+__device__ __forceinline__ uint32_t ranged_bucket(uint32_t x, int shift, uint32_t mul, uint32_t mask)
+{
+    const uint32_t q = mul ? __umulhi(x, mul) : (x >> shift);
+    return q < mask ? q : mask;
+}
+__device__ __forceinline__ uint32_t ranged_bucket(uint64_t x, int shift, uint64_t mul, uint32_t mask)
+{
+    const uint64_t q = mul ? __umul64hi(x, mul) : (x >> shift);
+    return q < mask ? static_cast<uint32_t>(q) : mask;
+}
+
 // Workgroup -> tile.  Hardware deals consecutive workgroup ids round-robin over the 8
 // XCDs (observed, speed only).  With the remap every XCD walks its own contiguous range
 // of tiles, so the seam between the output runs of tiles t and t+1 (same digit,
@@ -130,11 +145,20 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* w
 // Counting uses LDS atomics on 32 lane-private replicas of the 16 counters (row stride
 // 17 words): a wave whose keys all share one digit (Zeros, Range) still spreads over 32
 // banks instead of serialising on one address.
-template <typename Key, int THREADS, int KPT>
+// RANGED (multi-GPU partition only): bucket = ranged_bucket((key ^ flip) - lo) — 16 equal-width
+// buckets over the global key range [lo, hi], a monotone function of the key.
+template <typename Key, int THREADS, int KPT, bool RANGED = false>
 __global__ __launch_bounds__(THREADS) void histogram_kernel(const Key* __restrict__ keys, uint32_t* __restrict__ table,
                                                              uint64_t n, uint32_t ntiles, uint32_t tiles_per_xcd,
-                                                             int remap, int shift, Key flip, uint32_t mask)
+                                                             int remap, int shift, Key flip, uint32_t mask, Key lo, Key mul)
 {
+    auto dig = [=](Key key) -> uint32_t {
+        if constexpr (RANGED) {
+            return ranged_bucket(static_cast<Key>((key ^ flip) - lo), shift, mul, mask);
+        } else {
+            return digit_of(key, shift, flip, mask);
+        }
+    };
     constexpr int TILE = THREADS * KPT;
     constexpr int VEC = KeyVec<Key>::N;
     constexpr int NV = KPT / VEC;
@@ -166,7 +190,7 @@ __global__ __launch_bounds__(THREADS) void histogram_kernel(const Key* __restric
         for (int j = 0; j < NV; ++j) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-                atomicAdd(&mine[digit_of(v[j].k[e], shift, flip, mask)], 1u);
+                atomicAdd(&mine[dig(v[j].k[e])], 1u);
             }
         }
     } else {
@@ -176,7 +200,7 @@ __global__ __launch_bounds__(THREADS) void histogram_kernel(const Key* __restric
             for (int e = 0; e < VEC; ++e) {
                 const uint32_t li = static_cast<uint32_t>(j) * THREADS * VEC + tid * VEC + e;
                 if (li < valid) {
-                    atomicAdd(&mine[digit_of(keys[base + li], shift, flip, mask)], 1u);
+                    atomicAdd(&mine[dig(keys[base + li])], 1u);
                 }
             }
         }
@@ -400,15 +424,23 @@ constexpr int reorder_min_waves()
 // HBM.  A run (one digit of one source tile) covers at most two output tiles, so the
 // counts are first gathered in LDS as [digit][segment 0/1][next digit] and then flushed
 // with one global atomic per non-zero counter (16 consecutive lanes -> one 64-B segment).
-template <typename Key, int THREADS, int KPT, bool PAYLOAD, bool LOOKAHEAD>
+template <typename Key, int THREADS, int KPT, bool PAYLOAD, bool LOOKAHEAD, bool RANGED = false>
 __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYLOAD>())) void reorder_kernel(const Key* __restrict__ in, Key* __restrict__ out,
                                                            const uint32_t* __restrict__ pin, uint32_t* __restrict__ pout,
                                                            const uint32_t* __restrict__ table, uint64_t n, uint32_t ntiles,
                                                            uint32_t tiles_per_xcd, int remap, int shift, Key flip, uint32_t mask,
                                                            uint32_t* __restrict__ next_counts, int next_shift,
-                                                           const uint32_t* __restrict__ globsum)
+                                                           const uint32_t* __restrict__ globsum, Key lo, Key mul)
 {
     using L = ReorderLayout<Key, THREADS, KPT>;
+    static_assert(!(RANGED && LOOKAHEAD), "the ranged bucket function is for the one-pass partition only");
+    auto dig = [=](Key key) -> uint32_t {
+        if constexpr (RANGED) {
+            return ranged_bucket(static_cast<Key>((key ^ flip) - lo), shift, mul, mask);
+        } else {
+            return digit_of(key, shift, flip, mask);
+        }
+    };
     constexpr int TILE = L::TILE;
     constexpr int VEC = KeyVec<Key>::N;
     constexpr int NV = KPT / VEC;
@@ -553,7 +585,7 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
     auto counter_index = [tid](uint32_t d) { return (((d & 7u) * THREADS + tid) << 1) + (d >> 3); };
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
-        const uint32_t ci = counter_index(digit_of(k[i], shift, flip, mask));
+        const uint32_t ci = counter_index(dig(k[i]));
         const uint32_t c = cnt16[ci];
         slot[i] = c;
         cnt16[ci] = static_cast<uint16_t>(c + 1);
@@ -599,7 +631,7 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
         uint32_t first_of_digit[KPT];
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
-            first_of_digit[i] = cnt16[counter_index(digit_of(k[i], shift, flip, mask))];
+            first_of_digit[i] = cnt16[counter_index(dig(k[i]))];
         }
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
@@ -626,14 +658,14 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
         RunBase rb[KPT];
 #pragma unroll
         for (int r = 0; r < KPT; ++r) {
-            rb[r] = runs[digit_of(okey[r], shift, flip, mask)];
+            rb[r] = runs[dig(okey[r])];
         }
 #pragma unroll
         for (int r = 0; r < KPT; ++r) {
             const uint32_t i = static_cast<uint32_t>(r) * THREADS + tid;
             g[r] = rb[r].gbase + i;
             if constexpr (LOOKAHEAD) {
-                la_idx[r] = (digit_of(okey[r], shift, flip, mask) << 5) + (((g[r] >> L::TILE_SHIFT) - rb[r].run_tile) << 4) +
+                la_idx[r] = (dig(okey[r]) << 5) + (((g[r] >> L::TILE_SHIFT) - rb[r].run_tile) << 4) +
                             digit_of(okey[r], next_shift, flip, static_cast<uint32_t>(kRadix - 1));
             }
         }
@@ -698,6 +730,55 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
 // ---------------------------------------------------------------------------
 // small utility kernels
 // ---------------------------------------------------------------------------
+// min / max of the keys in unsigned order (key ^ flip); one {min, max} pair per workgroup,
+// reduced on the host (multi-GPU partition: 16 equal-width buckets over the global range)
+constexpr int kRangeThreads = 256;
+template <typename Key>
+__global__ __launch_bounds__(kRangeThreads) void key_range_kernel(const Key* __restrict__ keys, uint64_t n, Key flip,
+                                                                   unsigned long long* __restrict__ partial)
+{
+    __shared__ unsigned long long smin[kRangeThreads / kWave], smax[kRangeThreads / kWave];
+    constexpr int VEC = KeyVec<Key>::N;
+    unsigned long long lo = ~0ull, hi = 0ull;
+    const uint64_t nvec = n / VEC;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        const KeyVec<Key> v = *reinterpret_cast<const KeyVec<Key>*>(keys + i * VEC);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const unsigned long long u = static_cast<unsigned long long>(static_cast<Key>(v.k[e] ^ flip));
+            lo = u < lo ? u : lo;
+            hi = u > hi ? u : hi;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < n - nvec * VEC) {      // ragged tail
+        const unsigned long long u = static_cast<unsigned long long>(static_cast<Key>(keys[nvec * VEC + threadIdx.x] ^ flip));
+        lo = u < lo ? u : lo;
+        hi = u > hi ? u : hi;
+    }
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        const unsigned long long ol = __shfl_xor(lo, off), oh = __shfl_xor(hi, off);
+        lo = ol < lo ? ol : lo;
+        hi = oh > hi ? oh : hi;
+    }
+    const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    if (lane == 0) {
+        smin[wave] = lo;
+        smax[wave] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < kRangeThreads / kWave; ++w) {
+            lo = smin[w] < lo ? smin[w] : lo;
+            hi = smax[w] > hi ? smax[w] : hi;
+        }
+        partial[2 * blockIdx.x] = lo;
+        partial[2 * blockIdx.x + 1] = hi;
+    }
+}
+
 template <typename Key>
 __global__ void fill_kernel(Key* __restrict__ dst, uint64_t first, uint64_t count, Key value)
 {

@@ -5,12 +5,18 @@ The reference has no multi-device path ("Parallelism strategies: non
 is the capability the north-star adds.  LSD passes are not independent
 across shards, but a most-significant-bits partition is, so the data path is:
 
-  1. every rank groups its shard by the top 4 key bits — ONE stable radix pass of the
-     same histogram/scan/reorder kernels (C ABI `rsx_partition`), which also yields the
-     16 bucket sizes;
+  0. every rank finds the min and max of its keys (`rsx_key_range`, one read) and the ranks
+     agree on the global range [lo, hi] (`all_gather` of 4 words).  If lo == hi all keys are
+     equal and nothing needs to move;
+  1. every rank groups its shard into 16 equal-width buckets over [lo, hi] —
+     bucket = ((key ^ sign) - lo) >> shift, a monotone function of the key — with ONE stable
+     pass of the same histogram/scan/reorder kernels (C ABI `rsx_partition_range`), which
+     also yields the 16 bucket sizes.  (Buckets on the top 4 key BITS would put small-range
+     or sorted inputs, e.g. `Range`, on a single rank);
   2. "histogram all-to-all": all ranks exchange their 16 bucket counts
      (`all_gather`, 16 x int64 per rank — latency-bound, KBs);
-  3. buckets are dealt to ranks as contiguous ranges (`bucket_owner`), so each rank's
+  3. buckets are dealt to ranks as contiguous ranges balanced on the global counts
+     (`balanced_owner`), so each rank's
      outgoing data is already contiguous per destination; `all_to_all_single` with
      split sizes moves the keys (and payloads) — every GPU talks to every peer over its
      own xGMI link at once, which suits the point-to-point fabric (a ring would be
@@ -40,12 +46,12 @@ def bucket_owner(world_size: int) -> list[int]:
     return [b * world_size // RADIX for b in range(RADIX)]
 
 
-def send_splits(bucket_offsets: list[int], world_size: int) -> list[int]:
+def send_splits(bucket_offsets: list[int], world_size: int, owner: list[int] | None = None) -> list[int]:
     """Number of local keys going to each rank, from the 17 exclusive bucket offsets of the
     partition pass."""
     if len(bucket_offsets) != RADIX + 1:
         raise ValueError("expected 17 bucket offsets")
-    owner = bucket_owner(world_size)
+    owner = owner or bucket_owner(world_size)
     out = [0] * world_size
     for b in range(RADIX):
         out[owner[b]] += bucket_offsets[b + 1] - bucket_offsets[b]
@@ -67,18 +73,66 @@ class ExchangePlan:
         return sum(self.recv)
 
 
-def plan_exchange(bucket_offsets: list[int], rank: int, world_size: int, dist, device) -> ExchangePlan:
-    """Steps 2 of the module docstring: all_gather of the per-rank send splits."""
+def global_key_range(local_lo: int, local_hi: int, world_size: int, dist, device) -> tuple[int, int]:
+    """Step 0: global [lo, hi] in unsigned sort order.  64-bit values travel as two 32-bit
+    halves in an int64 tensor; a rank without keys contributes (UINT64_MAX, 0)."""
+    if dist is None:
+        return local_lo, local_hi
     import torch
 
-    mine = send_splits(bucket_offsets, world_size)
-    if world_size == 1 and dist is None:
-        return ExchangePlan(send=mine, recv=mine)
-    t = torch.tensor(mine, dtype=torch.int64, device=device)
-    gathered = torch.empty(world_size * world_size, dtype=torch.int64, device=device)
+    m = 0xFFFFFFFF
+    t = torch.tensor([local_lo >> 32, local_lo & m, local_hi >> 32, local_hi & m], dtype=torch.int64, device=device)
+    gathered = torch.empty(4 * world_size, dtype=torch.int64, device=device)
     dist.all_gather_into_tensor(gathered, t)
-    table = gathered.cpu().view(world_size, world_size).tolist()
-    return ExchangePlan(send=mine, recv=recv_splits(table, rank))
+    rows = gathered.cpu().view(world_size, 4).tolist()
+    los = [(r[0] << 32) | r[1] for r in rows]
+    his = [(r[2] << 32) | r[3] for r in rows]
+    return min(los), max(his)
+
+
+def range_buckets(lo: int, hi: int, key_bits: int) -> tuple[int, int]:
+    """(shift, mul) of the 16 equal-width buckets over [lo, hi] (C ABI rsx_partition_range):
+    bucket(x) = mulhi(x, mul) with mul = floor(16 * 2^key_bits / (hi - lo + 1)); ranges of at
+    most 16 values use bucket(x) = x (shift 0, mul 0)."""
+    span1 = hi - lo + 1
+    if span1 <= RADIX:
+        return 0, 0
+    mul = (RADIX << key_bits) // span1
+    assert mul < (1 << key_bits) and ((hi - lo) * mul) >> key_bits < RADIX
+    return 0, mul
+
+
+def balanced_owner(global_counts: list[int], world_size: int) -> list[int]:
+    """Bucket -> rank as contiguous ranges cut where the running total crosses k/world of all
+    keys (every rank computes the same map from the same gathered counts)."""
+    total = sum(global_counts)
+    owner, run, rank = [], 0, 0
+    for c in global_counts:
+        # move on to the next rank once this one has its share, judged at the bucket's midpoint
+        while rank < world_size - 1 and (run + c / 2) * world_size >= (rank + 1) * total and total > 0:
+            rank += 1
+        owner.append(rank)
+        run += c
+    return owner
+
+
+def plan_exchange(bucket_offsets: list[int], rank: int, world_size: int, dist, device) -> ExchangePlan:
+    """Step 2 of the module docstring ("histogram all-to-all"): all ranks learn every rank's 16
+    bucket counts, deal the buckets to ranks in balanced contiguous ranges, and derive their
+    send and receive split sizes."""
+    import torch
+
+    counts = [bucket_offsets[b + 1] - bucket_offsets[b] for b in range(RADIX)]
+    if dist is None:
+        mine = send_splits(bucket_offsets, world_size)
+        return ExchangePlan(send=mine, recv=mine)
+    t = torch.tensor(counts, dtype=torch.int64, device=device)
+    gathered = torch.empty(world_size * RADIX, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(gathered, t)
+    table = gathered.cpu().view(world_size, RADIX).tolist()              # [source rank][bucket]
+    owner = balanced_owner([sum(row[b] for row in table) for b in range(RADIX)], world_size)
+    sends = [[sum(row[b] for b in range(RADIX) if owner[b] == dst) for dst in range(world_size)] for row in table]
+    return ExchangePlan(send=sends[rank], recv=recv_splits(sends, rank))
 
 
 class ShardedSorter:
@@ -105,8 +159,16 @@ class ShardedSorter:
         if self.world == 1 and not self.force_exchange:
             self.engine.sort_from(keys.data_ptr(), n, payload.data_ptr() if payload is not None else None)
             return n
-        offs = self.engine.partition(
-            keys.data_ptr(), n, self.key_bits - PARTITION_BITS, PARTITION_BITS, staging.data_ptr(),
+        lo, hi = self.engine.key_range(keys.data_ptr(), n)
+        lo, hi = global_key_range(lo, hi, self.world, self.dist, keys.device)
+        if lo >= hi:
+            # every key everywhere is the same value (or there are no keys): rank-order
+            # concatenation is already sorted and stable, nothing has to move
+            self.engine.sort_from(keys.data_ptr(), n, payload.data_ptr() if payload is not None else None)
+            return n
+        shift, mul = range_buckets(lo, hi, self.key_bits)
+        offs = self.engine.partition_range(
+            keys.data_ptr(), n, lo, shift, mul, staging.data_ptr(),
             payload.data_ptr() if payload is not None else None,
             staging_payload.data_ptr() if staging_payload is not None else None)
         plan = plan_exchange(offs, self.rank, self.world, self.dist, keys.device)

@@ -38,6 +38,19 @@ def test_bucket_owner_and_splits():
     assert d.send_splits(offs, 4) == [40, 40, 40, 40]
     assert d.send_splits(offs, 3) == [60, 50, 50]
     assert d.recv_splits([[1, 2], [3, 4]], 0) == [1, 3] and d.recv_splits([[1, 2], [3, 4]], 1) == [2, 4]
+    assert d.range_buckets(0, 15, 32) == (0, 0) and d.range_buckets(7, 7, 64) == (0, 0)
+    for lo, hi, bits in [(0, 999, 32), (123, 123 + 2**31, 32), (0, 2**32 - 1, 32), (0, 2**64 - 1, 64), (5, 5 + 2**40, 64), (0, 16, 32)]:
+        shift, mul = d.range_buckets(lo, hi, bits)
+        assert shift == 0 and 0 < mul < 2**bits
+        assert ((hi - lo) * mul) >> bits == 15 or hi - lo < 32          # the top key lands in the last bucket
+        assert [((v - lo) * mul) >> bits for v in (lo, hi)] == sorted([((v - lo) * mul) >> bits for v in (lo, hi)])
+    assert d.balanced_owner([10] * 16, 8) == [0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7]
+    own = d.balanced_owner([100] + [0] * 15, 4)
+    assert own == sorted(own) and 0 <= own[0] < 4               # one hot bucket: any single owner, still monotone
+    own = d.balanced_owner([5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 0, 0, 0, 0], 2)        # 12 used buckets
+    assert own == sorted(own) and own.count(0) == 6
+    own = d.balanced_owner([0] * 16, 3)
+    assert own == sorted(own)
     with pytest.raises(ValueError):
         d.bucket_owner(17)
 
@@ -68,6 +81,29 @@ class _CpuEngineDouble:
             self._view(d_payload_out, n, np.uint32)[:] = self._view(d_payload, n, np.uint32)[order]
         counts = np.bincount(d, minlength=1 << bits)
         return [0] + [int(v) for v in np.cumsum(counts)]
+
+    def _biased(self, keys):
+        u = keys.view(np.uint32 if self.dtype.itemsize == 4 else np.uint64)
+        if self.dtype.kind == "i":
+            u = u ^ u.dtype.type(1 << (self.dtype.itemsize * 8 - 1))
+        return u
+
+    def key_range(self, d_keys, n):
+        if n == 0:
+            return (1 << 64) - 1, 0
+        u = self._biased(self._view(d_keys, n, self.dtype))
+        return int(u.min()), int(u.max())
+
+    def partition_range(self, d_keys, n, lo, shift, mul, d_keys_out, d_payload=None, d_payload_out=None):
+        keys = self._view(d_keys, n, self.dtype)
+        bits = self.dtype.itemsize * 8
+        x = [int(v) - lo for v in self._biased(keys)]
+        d = np.array([min(((v * mul) >> bits) if mul else (v >> shift), 15) for v in x], dtype=np.int64)
+        order = np.argsort(d, kind="stable")
+        self._view(d_keys_out, n, self.dtype)[:] = keys[order]
+        if d_payload:
+            self._view(d_payload_out, n, np.uint32)[:] = self._view(d_payload, n, np.uint32)[order]
+        return [0] + [int(v) for v in np.cumsum(np.bincount(d, minlength=16))]
 
     def sort_from(self, d_keys, n, d_payload=None):
         keys = self._view(d_keys, n, self.dtype).copy()
@@ -119,7 +155,9 @@ def _worker(rank, world, port, dtype, kind, with_payload, n_per_rank, q):
     ("int32", "SeededUniform", True),
     ("uint64", "SeededUniform", True),
     ("int64", "Random", False),       # all keys are small non-negative: lands on few ranks
-    ("uint32", "Zeros", True),        # every key equal: one rank receives everything
+    ("uint32", "Zeros", True),        # every key equal: nothing moves
+    ("int32", "Range", True),         # small range at the bottom of the key space: ranged buckets balance it
+    ("uint64", "InvertedRange", False),
 ])
 def test_sharded_sort_world2(dtype, kind, with_payload):
     import torch.multiprocessing as mp
@@ -140,6 +178,8 @@ def test_sharded_sort_world2(dtype, kind, with_payload):
     got = np.concatenate([o[2] for o in outs])
     assert sum(o[1] for o in outs) == full.size
     assert np.array_equal(got, np.sort(full, kind="stable"))
+    if kind in ("Range", "InvertedRange", "SeededUniform"):
+        assert max(o[1] for o in outs) <= 0.6 * full.size        # ranged buckets keep the ranks balanced
     if with_payload:
         got_p = np.concatenate([o[3] for o in outs])
         assert np.array_equal(got_p, np.argsort(full, kind="stable").astype(np.uint32))   # global stable argsort

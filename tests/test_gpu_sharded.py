@@ -50,7 +50,8 @@ class _RankDist:
         self.hub.barrier.wait()
 
 
-@pytest.mark.parametrize("dtype,kind,with_payload", [("uint32", "SeededUniform", False), ("int64", "SeededUniform", True), ("uint32", "Zeros", True)])
+@pytest.mark.parametrize("dtype,kind,with_payload", [("uint32", "SeededUniform", False), ("int64", "SeededUniform", True), ("uint32", "Zeros", True),
+                                                      ("int32", "Range", True), ("uint64", "InvertedRange", False)])
 def test_two_ranks_on_one_gpu(rsx, oracle, dtype, kind, with_payload):
     import torch
     from radix_sort_amd.distributed import ShardedSorter
@@ -124,3 +125,33 @@ def test_bench_through_rccl_single_rank():
     line = json.loads([l for l in proc.stdout.splitlines() if l.startswith("{")][-1])
     assert line["config"]["verified"] is True and line["n_gpus"] == 1
     assert "all_to_all" in line["config"]["parallelism"] and line["value"] > 0
+
+
+@pytest.mark.parametrize("dt", ["uint32", "int32", "uint64", "int64"])
+def test_key_range_and_ranged_partition(rsx, oracle, dt):
+    import torch
+    rng = np.random.default_rng(3)
+    info = np.iinfo(dt)
+    n = 77777
+    base = int(info.min) + (int(info.max) - int(info.min)) // 3
+    keys = (base + rng.integers(0, 1 << 20, size=n)).astype(dt)
+    signed = {"uint32": np.int32, "uint64": np.int64}.get(np.dtype(dt).name)
+    tk = torch.from_numpy(keys.view(signed) if signed else keys).cuda()
+    out = torch.empty_like(tk)
+    u = keys.view(np.uint32 if keys.dtype.itemsize == 4 else np.uint64).astype(np.uint64)
+    if keys.dtype.kind == "i":
+        u = u ^ np.uint64(1 << (keys.dtype.itemsize * 8 - 1))
+    with rsx.Engine(dt, n) as e:
+        e.set_stream(torch.cuda.current_stream().cuda_stream)
+        lo, hi = e.key_range(tk.data_ptr(), n)
+        assert (lo, hi) == (int(u.min()), int(u.max()))
+        from radix_sort_amd.distributed import range_buckets
+        bits = keys.dtype.itemsize * 8
+        shift, mul = range_buckets(lo, hi, bits)
+        offs = e.partition_range(tk.data_ptr(), n, lo, shift, mul, out.data_ptr())
+        torch.cuda.synchronize()
+    d = np.array([min(((int(v) - lo) * mul) >> bits, 15) for v in u], dtype=np.int64)
+    got = out.cpu().numpy().view(keys.dtype)
+    assert np.array_equal(got, keys[np.argsort(d, kind="stable")])
+    assert offs == [0] + [int(v) for v in np.cumsum(np.bincount(d, minlength=16))]
+    assert min(np.diff(offs)) > 0                      # all 16 buckets used: the range is covered evenly
