@@ -22,7 +22,9 @@
 // 16 private 16-bit counters in LDS, a raking DPP scan over the [digit][thread]
 // counters yields every key's slot in the tile-local sorted order, keys are staged
 // through LDS in that order, and the tile leaves as (up to) 16 runs of consecutive
-// addresses.  HBM sees 16-byte/lane coalesced loads and run-coalesced stores.
+// addresses.  HBM sees 16-byte loads of whole 64-byte per-lane rows and run-coalesced
+// stores.  Inside rsx_sort the reorder of pass p also counts pass p+1's digits per
+// output tile (look-ahead), so only the first pass reads the keys for a histogram.
 //
 // No MFMA: this is an integer permutation bounded by HBM bandwidth.
 #pragma once
