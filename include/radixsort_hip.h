@@ -57,6 +57,10 @@ typedef enum rsx_option {
     RSX_OPT_XCD_REMAP = 1,    /* 1 (default): consecutive tiles run on one XCD (L2 merges run seams) */
     RSX_OPT_FIRST_PASS = 2,   /* first pass of rsx_sort (default 0) */
     RSX_OPT_LAST_PASS = 3,    /* one past the last pass of rsx_sort (default bits/4) */
+    RSX_OPT_REF_DIAGNOSTICS = 5, /* 1: rsx_download fills hist_out / globsum_out in the REFERENCE's geometry
+                                 (16384-word [digit][group][item] table after paste, 512 scanned block sums,
+                                 src/RadixSortGPU.cpp:412-428), recomputed from the last pass's input; needs a key
+                                 count that is a multiple of 1024.  0 (default): the engine's own [digit][tile] table. */
     RSX_OPT_LOOKAHEAD = 4     /* 1 (default): inside rsx_sort the reorder of pass p also counts pass p+1's digits per
                                  output tile, so only the first pass runs the histogram kernel; 0: every pass runs
                                  histogram -> scan -> paste -> reorder separately.  Results are identical. */

@@ -104,6 +104,11 @@ struct rsx_engine {
     uint32_t* globsum = nullptr;                // block sums of the table scan
     uint32_t* temp = nullptr;                   // grand total of scan #2
     uint32_t* counts_next = nullptr;            // look-ahead histogram of the next pass, [tile][digit]
+    uint32_t* ref_table = nullptr;              // diagnostics in the reference's [digit][group][item] geometry
+    uint32_t* ref_globsum = nullptr;
+    const void* last_in = nullptr;              // input buffer and shift of the most recent reorder
+    int last_shift = 0;
+    int ref_diag = 0;                           // RSX_OPT_REF_DIAGNOSTICS
     unsigned long long* range_dev = nullptr;    // per-workgroup {min, max} of rsx_key_range
     unsigned long long* range_host = nullptr;   // pinned mirror
     uint32_t* starts_dev = nullptr;             // 16 bucket starts (rsx_partition)
@@ -258,6 +263,8 @@ int launch_reorder_t(rsx_engine* e, const void* in, void* out, const uint32_t* p
 {
     using L = rsx::ReorderLayout<Key, kTileThreads, kKeysPerThread>;
     const Grid g = grid_for(e, count);
+    e->last_in = in;
+    e->last_shift = shift;
     Bracket b(e, PH_REORDER);
     hipLaunchKernelGGL((rsx::reorder_kernel<Key, kTileThreads, kKeysPerThread, PAYLOAD, LOOKAHEAD, RANGED>), dim3(g.blocks), dim3(kTileThreads),
                        L::BYTES, e->stream, static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->table, count,
@@ -500,6 +507,10 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
         return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(globsum)", err);
     if ((err = hipMalloc(reinterpret_cast<void**>(&e->temp), 64)) != hipSuccess)
         return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(temp)", err);
+    if ((err = hipMalloc(reinterpret_cast<void**>(&e->ref_table), rsx::kRefTable * 4)) != hipSuccess)
+        return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(ref table)", err);
+    if ((err = hipMalloc(reinterpret_cast<void**>(&e->ref_globsum), rsx::kRefSplit * 4)) != hipSuccess)
+        return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(ref globsum)", err);
     if ((err = hipMalloc(reinterpret_cast<void**>(&e->range_dev), kRangeBlocks * 16)) != hipSuccess)
         return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(range)", err);
     if ((err = hipHostMalloc(reinterpret_cast<void**>(&e->range_host), kRangeBlocks * 16, hipHostMallocDefault)) != hipSuccess)
@@ -555,6 +566,8 @@ int rsx_destroy(rsx_engine* e)
     if (e->temp && hipFree(e->temp) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->starts_dev && hipFree(e->starts_dev) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->range_dev && hipFree(e->range_dev) != hipSuccess) status = RSX_CLEANUP_FAILED;
+    if (e->ref_table && hipFree(e->ref_table) != hipSuccess) status = RSX_CLEANUP_FAILED;
+    if (e->ref_globsum && hipFree(e->ref_globsum) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->range_host && hipHostFree(e->range_host) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->starts_host && hipHostFree(e->starts_host) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->own_stream && e->stream && hipStreamDestroy(e->stream) != hipSuccess) status = RSX_CLEANUP_FAILED;
@@ -583,6 +596,7 @@ int rsx_set_option(rsx_engine* e, int option, int64_t value)
     case RSX_OPT_PROFILE: e->profile = value < 0 || value > 2 ? 1 : static_cast<int>(value); return RSX_OK;
     case RSX_OPT_XCD_REMAP: e->xcd_remap = value != 0; return RSX_OK;
     case RSX_OPT_LOOKAHEAD: e->lookahead = value != 0; return RSX_OK;
+    case RSX_OPT_REF_DIAGNOSTICS: e->ref_diag = value != 0; return RSX_OK;
     case RSX_OPT_FIRST_PASS:
         if (value < 0 || value > e->passes()) return fail(RSX_CALCULATION_FAILED, "rsx_set_option: first pass out of range");
         e->first_pass = static_cast<int>(value);
@@ -677,6 +691,30 @@ int rsx_download(rsx_engine* e, void* host_keys_out, uint32_t* host_perm_out, ui
     if (e->n > 0 && host_perm_out && e->has_payload) {
         RSX_TRY(hipMemcpyAsync(host_perm_out, e->result_perm, static_cast<size_t>(e->n) * 4, hipMemcpyDeviceToHost, e->stream),
                 RSX_DATA_DOWNLOAD_FAILED);
+    }
+    if (e->ref_diag && ((hist_out && hist_cap) || (globsum_out && globsum_cap))) {
+        // the reference's m_hHistograms / m_hGlobsum: recomputed in its own geometry from the last pass's input
+        if (e->n == 0 || e->n % rsx::kRefVps != 0 || !e->last_in)
+            return fail(RSX_DATA_DOWNLOAD_FAILED, "rsx_download: reference-geometry diagnostics need a finished pass over a multiple of 1024 keys");
+        if (e->key_bytes == 4) {
+            hipLaunchKernelGGL(rsx::ref_histogram_kernel<uint32_t>, dim3(rsx::kRefVps), dim3(256), 0, e->stream,
+                               static_cast<const uint32_t*>(e->last_in), e->ref_table, e->n, e->last_shift, flip_mask<uint32_t>(e));
+        } else {
+            hipLaunchKernelGGL(rsx::ref_histogram_kernel<uint64_t>, dim3(rsx::kRefVps), dim3(256), 0, e->stream,
+                               static_cast<const uint64_t*>(e->last_in), e->ref_table, e->n, e->last_shift, flip_mask<uint64_t>(e));
+        }
+        hipLaunchKernelGGL(rsx::ref_scan_kernel, dim3(1), dim3(1024), 0, e->stream, e->ref_table, e->ref_globsum);
+        RSX_TRY(hipGetLastError(), RSX_DATA_DOWNLOAD_FAILED);
+        if (hist_out && hist_cap) {
+            RSX_TRY(hipMemcpyAsync(hist_out, e->ref_table, std::min<uint64_t>(hist_cap, rsx::kRefTable) * 4, hipMemcpyDeviceToHost, e->stream),
+                    RSX_DATA_DOWNLOAD_FAILED);
+        }
+        if (globsum_out && globsum_cap) {
+            RSX_TRY(hipMemcpyAsync(globsum_out, e->ref_globsum, std::min<uint64_t>(globsum_cap, rsx::kRefSplit) * 4, hipMemcpyDeviceToHost, e->stream),
+                    RSX_DATA_DOWNLOAD_FAILED);
+        }
+        RSX_TRY(hipStreamSynchronize(e->stream), RSX_DATA_DOWNLOAD_FAILED);
+        return RSX_OK;
     }
     if (hist_out && hist_cap) {
         const uint64_t live = static_cast<uint64_t>(RSX_RADIX) * e->ntiles(e->n);

@@ -732,6 +732,68 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
 // ---------------------------------------------------------------------------
 // small utility kernels
 // ---------------------------------------------------------------------------
+// Diagnostics in the REFERENCE's geometry (RadixSortGPU.cpp:412-428 downloads them after every
+// sort): 1024 virtual processors with contiguous sub-lists of n/1024 keys, counter table
+// [digit][group][item] = [digit][vp], its global exclusive scan ("pasted" table, 16384 words)
+// and the scanned sums of the 512 blocks of 32 entries (globsum).  Recomputed on request from the
+// input of the last pass, which still sits in the other ping-pong buffer.
+constexpr int kRefVps = 1024;
+constexpr int kRefTable = kRadix * kRefVps;      // _RADIX * _NUM_ITEMS = 16384
+constexpr int kRefSplit = 512;                   // _NUM_HISTOSPLIT
+
+template <typename Key>
+__global__ __launch_bounds__(256) void ref_histogram_kernel(const Key* __restrict__ keys, uint32_t* __restrict__ ref_table,
+                                                             uint64_t n, int shift, Key flip)
+{
+    __shared__ uint32_t cnt[kRadix];
+    const uint32_t vp = blockIdx.x;
+    const uint64_t sub = n / kRefVps;
+    if (threadIdx.x < kRadix) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t local[kRadix] = {};
+    for (uint64_t j = threadIdx.x; j < sub; j += blockDim.x) {
+        const uint32_t d = digit_of(keys[vp * sub + j], shift, flip, static_cast<uint32_t>(kRadix - 1));
+#pragma unroll
+        for (int v = 0; v < kRadix; ++v) {
+            local[v] += (d == static_cast<uint32_t>(v)) ? 1u : 0u;
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < kRadix; ++v) {
+        if (local[v]) atomicAdd(&cnt[v], local[v]);
+    }
+    __syncthreads();
+    if (threadIdx.x < kRadix) {
+        ref_table[threadIdx.x * kRefVps + vp] = cnt[threadIdx.x];     // items*(ir*groups+gr)+it == ir*1024 + vp
+    }
+}
+
+// exclusive scan of the 16384 counters in place (= the table after scan #1, scan #2 and paste);
+// globsum[b] = scanned sum of block b = the pasted value of the block's first entry
+__global__ __launch_bounds__(1024) void ref_scan_kernel(uint32_t* __restrict__ ref_table, uint32_t* __restrict__ ref_globsum)
+{
+    __shared__ uint32_t wtot[1024 / kWave];
+    const uint32_t tid = threadIdx.x;
+    uint32_t v[kRadix];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < kRadix; ++i) {
+        const uint32_t c = ref_table[tid * kRadix + i];
+        v[i] = sum;
+        sum += c;
+    }
+    uint32_t total;
+    const uint32_t before = block_exclusive_scan<1024>(sum, wtot, total);
+#pragma unroll
+    for (int i = 0; i < kRadix; ++i) {
+        ref_table[tid * kRadix + i] = v[i] + before;
+    }
+    // blocks of kRefTable / kRefSplit = 32 entries: thread tid owns entries [16 tid, 16 tid + 16)
+    if ((tid & 1u) == 0) {
+        ref_globsum[tid >> 1] = before;
+    }
+}
+
 // min / max of the keys in unsigned order (key ^ flip); one {min, max} pair per workgroup,
 // reduced on the host (multi-GPU partition: 16 equal-width buckets over the global range)
 constexpr int kRangeThreads = 256;

@@ -59,6 +59,7 @@ OperationStatus RadixSortGPU<DataType>::initialize(hipc::Device Device, hipc::Co
     }
     rsx_resize(mEngine, mNumberKeysRounded);
     rsx_set_option(mEngine, RSX_OPT_PROFILE, 1);   // RuntimesGPU is always filled, as in the reference
+    rsx_set_option(mEngine, RSX_OPT_REF_DIAGNOSTICS, 1);   // m_hHistograms / m_hGlobsum in the reference's geometry
     mPinned = false;
     if (mPinHost) {
         const std::uint64_t keyBytes = static_cast<std::uint64_t>(mNumberKeysRounded) * sizeof(DataType);
@@ -137,10 +138,10 @@ OperationStatus RadixSortGPU<DataType>::uploadData(hipc::CommandQueue CommandQue
 template <typename DataType>
 void RadixSortGPU<DataType>::CopyDataFromDevice(hipc::CommandQueue)
 {
-    // keys, permutation, digit table (first _RADIX*_NUM_ITEMS words) and block sums (first
-    // _NUM_HISTOSPLIT words) of the last pass (src/RadixSortGPU.cpp:390-429).  The two
-    // diagnostic read-backs follow THIS engine's geometry ([digit][tile], 4096-entry scan
-    // blocks), not the reference's [digit][group][item]; nothing consumes them.
+    // keys, permutation, and the two diagnostic read-backs of the last pass: the pasted counter
+    // table (_RADIX*_NUM_ITEMS words, [digit][group][item]) and the scanned block sums
+    // (_NUM_HISTOSPLIT words) — src/RadixSortGPU.cpp:390-429.  The engine recomputes both in the
+    // reference's geometry (RSX_OPT_REF_DIAGNOSTICS); nothing consumes them, they are for parity.
     mLastStatus = rsx_download(mEngine, mHostSpans.m_hResultFromGPU.data(), mWithPermutation ? mHostSpans.h_Permut.data() : nullptr,
                                mHostSpans.m_hHistograms.data(), mHostSpans.m_hHistograms.data() ? Parameters::_RADIX * Parameters::_NUM_ITEMS : 0,
                                mHostSpans.m_hGlobsum.data(), mHostSpans.m_hGlobsum.data() ? Parameters::_NUM_HISTOSPLIT : 0);

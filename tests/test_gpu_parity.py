@@ -204,6 +204,29 @@ def test_lookahead_histogram_equals_separate_histogram_passes(mod, oracle, dt, n
         assert np.array_equal(outs[1][1], np.argsort(keys, kind="stable").astype(np.uint32))
 
 
+@pytest.mark.parametrize("dt,n", [("uint32", 65536), ("int32", 1024), ("uint64", 1 << 20), ("int64", 10240)])
+def test_reference_geometry_diagnostics(mod, oracle, dt, n):
+    """m_hHistograms / m_hGlobsum as the reference downloads them (RadixSortGPU.cpp:412-428):
+    16384-word pasted [digit][group][item] table and 512 scanned block sums of the LAST pass,
+    against the host emulation of the reference's pass structure; for Random<uint32> 2^16 also
+    the sample values the survey recorded from that emulation."""
+    keys = oracle.dataset("Random", dt, n)
+    want_sorted, want_table, want_gs = oracle.emulate_reference_gpu(keys)
+    for la in (1, 0):
+        with mod.Engine(dt, n) as e:
+            e.set_option(mod.OPT_LOOKAHEAD, la)
+            e.set_option(mod.OPT_REF_DIAGNOSTICS, 1)
+            e.upload(keys)
+            e.sort()
+            got, table, gs = e.download(hist_cap=16384, globsum_cap=512)
+        assert np.array_equal(got, want_sorted)
+        assert np.array_equal(table, want_table)
+        assert np.array_equal(gs, want_gs)
+    if dt == "uint32" and n == 65536:
+        assert [int(v) for v in table[:4]] == [0, 5, 11, 17] and int(table[16383]) == 65534
+        assert int(gs[1]) == 121 and int(gs[511]) == 65400
+
+
 # --------------------------------------------------------------------------- reference semantics
 def test_fill_pad_value_and_rounded_length(mod, oracle):
     """padGPUData writes max()-1 from a byte offset (RadixSortGPU.cpp:270-285); the sort

@@ -127,6 +127,13 @@ def test_reference_gpu_structure_emulation(oracle):
         assert int(table[-1]) <= x.size
 
 
+def test_reference_gpu_emulation_matches_survey_samples(oracle):
+    # SURVEY §8c, "intermediate-buffer goldens": Random<u32> n=65536 after the last pass
+    _, table, gs = oracle.emulate_reference_gpu(oracle.dataset("Random", "uint32", 65536))
+    assert [int(v) for v in table[:4]] == [0, 5, 11, 17] and int(table[16383]) == 65534
+    assert int(gs[1]) == 121 and int(gs[511]) == 65400
+
+
 def test_empty_and_single(oracle):
     for dt in DT:
         assert oracle.radix_sort(np.array([], dtype=dt)).size == 0
