@@ -370,3 +370,70 @@ def test_full_size_2pow28_uint64_with_payload(mod, oracle):
     assert np.array_equal(keys[ps], ks)               # payload followed its key
     ties = np.flatnonzero(ks[:-1] == ks[1:])
     assert bool(np.all(ps[ties] < ps[ties + 1]))      # stability on equal keys
+
+
+# --------------------------------------------------------------------------- extremes
+def test_maximum_length_2pow32_minus_1024(mod):
+    """Largest length the uint32_t API admits (Resize keeps n a multiple of 1024 below 2^32): every
+    32-bit slot computation runs at its edge.  Keys are generated and checked on the device
+    (torch is the checker's plumbing here); sortedness + sum/xor checksums, chunked."""
+    import torch
+    n = (1 << 32) - 1024
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60 * (1 << 30):
+        pytest.skip("needs ~50 GiB of HBM")
+    gen = torch.Generator(device="cuda").manual_seed(1234)
+    keys = torch.empty(n, dtype=torch.int32, device="cuda")
+    chunk = 1 << 28
+    for lo in range(0, n, chunk):
+        hi = min(n, lo + chunk)
+        keys[lo:hi] = torch.randint(-(1 << 31), (1 << 31) - 1, (hi - lo,), generator=gen, dtype=torch.int64, device="cuda").to(torch.int32)
+    out = torch.empty_like(keys)
+    with mod.Engine("uint32", n) as e:
+        e.set_stream(torch.cuda.current_stream().cuda_stream)
+        e.sort_from(keys.data_ptr(), n)
+        e.copy_result(out.data_ptr())
+        torch.cuda.synchronize()
+    sign = torch.tensor(-(1 << 31), dtype=torch.int32, device="cuda")
+    s_in = s_out = 0
+    prev_last = None
+    for lo in range(0, n, chunk):
+        hi = min(n, lo + chunk)
+        a, b = keys[lo:hi], out[lo:hi]
+        s_in += int(a.to(torch.int64).sum()); s_out += int(b.to(torch.int64).sum())
+        u = torch.bitwise_xor(b, sign)                      # unsigned order as signed order
+        assert bool((u[:-1] <= u[1:]).all()), lo
+        if prev_last is not None:
+            assert prev_last <= int(u[0])
+        prev_last = int(u[-1])
+    assert s_in == s_out                                     # same multiset sum
+    # exact multiset check on a sample of values: counts of a few probe keys agree
+    for probe in (0, 1, -1, 123456789, -(1 << 31), (1 << 31) - 1):
+        assert int((keys == probe).sum()) == int((out == probe).sum())
+
+
+def test_engine_reuse_and_concurrent_engines(mod, oracle):
+    """One engine sorts inputs of different lengths back to back; two engines on two streams run
+    at the same time without sharing state (SURVEY §8b threading: handles share nothing)."""
+    import torch
+    with mod.Engine("uint32", 1 << 20) as e:
+        for n in (1 << 20, 1000, 4097, 1 << 18, 1):
+            keys = oracle.dataset("SeededUniform", "uint32", n, seed=n)
+            e.upload(keys)
+            e.sort()
+            assert np.array_equal(e.download(), np.sort(keys)), n
+    a = oracle.dataset("Random", "int64", 300000)
+    b = oracle.dataset("SeededUniform", "uint32", 500001)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    ta = torch.from_numpy(a).cuda()
+    tb = torch.from_numpy(b.view(np.int32)).cuda()
+    torch.cuda.synchronize()
+    with mod.Engine("int64", a.size) as e1, mod.Engine("uint32", b.size) as e2:
+        e1.set_stream(s1.cuda_stream)
+        e2.set_stream(s2.cuda_stream)
+        for _ in range(3):
+            e1.sort_from(ta.data_ptr(), a.size)
+            e2.sort_from(tb.data_ptr(), b.size)
+        torch.cuda.synchronize()
+        assert np.array_equal(e1.download(), np.sort(a))
+        assert np.array_equal(e2.download(), np.sort(b))
