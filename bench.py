@@ -128,7 +128,10 @@ def main() -> None:
     from radix_sort_amd.distributed import ShardedSorter
     capacity = 2 * n if sharded else n
     eng = rsx.Engine(args.dtype, capacity, payload=args.payload, device=local_rank)
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    # a real (non-null) stream: sorts, RCCL collectives and the engine's HIP events all live on it
+    stream = torch.cuda.Stream(device=device)
+    torch.cuda.set_stream(stream)
+    eng.set_stream(stream.cuda_stream)
     # timed region: HIP events bracket only the graded reorder launches (8 pairs per sort);
     # the per-phase table below comes from a fully instrumented step after it
     eng.set_option(rsx.OPT_PROFILE, 0 if args.no_events else 2)

@@ -61,6 +61,10 @@ typedef enum rsx_option {
                                  (16384-word [digit][group][item] table after paste, 512 scanned block sums,
                                  src/RadixSortGPU.cpp:412-428), recomputed from the last pass's input; needs a key
                                  count that is a multiple of 1024.  0 (default): the engine's own [digit][tile] table. */
+    RSX_OPT_GRAPH = 6,        /* 1: rsx_sort / rsx_sort_from of at most 2^22 keys are captured once into a hipGraph and
+                                 replayed; ignored while profiling and on the null stream.  Default 0: measured on
+                                 MI355X the replay is no faster than eager launches (the ~3 us dependent-kernel
+                                 boundary, not host launch cost, sets the 0.1 ms floor of a 33-kernel sort). */
     RSX_OPT_LOOKAHEAD = 4     /* 1 (default): inside rsx_sort the reorder of pass p also counts pass p+1's digits per
                                  output tile, so only the first pass runs the histogram kernel; 0: every pass runs
                                  histogram -> scan -> paste -> reorder separately.  Results are identical. */

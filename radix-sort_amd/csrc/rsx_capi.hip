@@ -85,6 +85,18 @@ void stat_update(rsx_phase_stat& s, double ms)
 
 }  // namespace
 
+struct GraphEntry {      // one captured rsx_sort chain
+    const void* in;
+    const uint32_t* pin;
+    uint64_t n;
+    int cur, first, last, flags;
+    hipStream_t stream;
+    hipGraphExec_t exec;
+    int end_cur;
+    const void* end_last_in;
+    int end_last_shift;
+};
+
 struct rsx_engine {
     int device = 0;
     int key_bytes = 4;
@@ -126,6 +138,8 @@ struct rsx_engine {
     int first_pass = 0;
     int last_pass = 0;
 
+    int use_graph = 0;          // RSX_OPT_GRAPH: replay sorts of <= 2^22 keys from a captured hipGraph (measured: no gain, off)
+    std::vector<GraphEntry> graphs;
     std::vector<EventPair> pending;
     std::vector<hipEvent_t> pool;
     rsx_phase_stat stats[PH_COUNT];
@@ -345,7 +359,7 @@ int key_range(rsx_engine* e, const void* d_keys, uint64_t n, uint64_t* lo, uint6
 }
 
 template <typename Key>
-int sort_chain(rsx_engine* e, const void* ext_keys, const uint32_t* ext_perm, uint64_t count)
+int sort_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext_perm, uint64_t count)
 {
     // Ping-pong.  With external input the first pass reads the caller's buffer (never
     // written) and the chain continues inside the engine's two buffers.
@@ -394,6 +408,67 @@ int sort_chain(rsx_engine* e, const void* ext_keys, const uint32_t* ext_perm, ui
     }
     e->result_keys = e->keys[e->cur];
     e->result_perm = e->has_payload ? e->perm[e->cur] : nullptr;
+    return RSX_OK;
+}
+
+// Small sorts are launch-bound (about 30 launches of a few microseconds each): capture the
+// whole pass loop once into a hipGraph and replay it.  A graph is keyed by everything its
+// nodes baked in; replaying it also replays the chain's effect on the engine's buffer names.
+constexpr uint64_t kGraphMaxKeys = 1ull << 22;
+
+template <typename Key>
+int sort_chain(rsx_engine* e, const void* ext_keys, const uint32_t* ext_perm, uint64_t count)
+{
+    // (the legacy null stream cannot be captured: PyTorch's default stream is that one)
+    const bool graphable = e->use_graph && e->profile == 0 && count > 0 && count <= kGraphMaxKeys && e->stream != nullptr;
+    if (!graphable) return sort_chain_enqueue<Key>(e, ext_keys, ext_perm, count);
+    GraphEntry key{};
+    key.in = ext_keys;
+    key.pin = ext_perm;
+    key.n = count;
+    key.cur = e->cur;
+    key.first = e->first_pass;
+    key.last = e->last_pass;
+    key.flags = (e->lookahead ? 1 : 0) | (e->xcd_remap ? 2 : 0) | (e->fold_paste ? 4 : 0) | (e->scan_zeroes ? 8 : 0);
+    key.stream = e->stream;
+    for (const GraphEntry& g : e->graphs) {
+        if (g.in == key.in && g.pin == key.pin && g.n == key.n && g.cur == key.cur && g.first == key.first && g.last == key.last &&
+            g.flags == key.flags && g.stream == key.stream) {
+            RSX_TRY(hipGraphLaunch(g.exec, e->stream), RSX_CALCULATION_FAILED);
+            e->cur = g.end_cur;
+            e->last_in = g.end_last_in;
+            e->last_shift = g.end_last_shift;
+            e->result_keys = e->keys[e->cur];
+            e->result_perm = e->has_payload ? e->perm[e->cur] : nullptr;
+            return RSX_OK;
+        }
+    }
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        e->use_graph = 0;                        // this stream cannot be captured: stay eager from now on
+        return sort_chain_enqueue<Key>(e, ext_keys, ext_perm, count);
+    }
+    const int rc = sort_chain_enqueue<Key>(e, ext_keys, ext_perm, count);
+    const hipError_t end = hipStreamEndCapture(e->stream, &graph);
+    if (rc != RSX_OK || end != hipSuccess || !graph) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc != RSX_OK ? rc : fail(RSX_CALCULATION_FAILED, "hipStreamEndCapture", end);
+    }
+    hipGraphExec_t exec = nullptr;
+    const hipError_t inst = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (inst != hipSuccess) return fail(RSX_CALCULATION_FAILED, "hipGraphInstantiate", inst);
+    key.exec = exec;
+    key.end_cur = e->cur;
+    key.end_last_in = e->last_in;
+    key.end_last_shift = e->last_shift;
+    if (e->graphs.size() >= 8) {                 // tiny cache: drop the oldest
+        (void)hipGraphExecDestroy(e->graphs.front().exec);
+        e->graphs.erase(e->graphs.begin());
+    }
+    e->graphs.push_back(key);
+    RSX_TRY(hipGraphLaunch(exec, e->stream), RSX_CALCULATION_FAILED);
     return RSX_OK;
 }
 
@@ -472,6 +547,7 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
     for (auto& s : e->stats) stat_reset(s);
     if (const char* env = std::getenv("RSX_XCD_REMAP")) e->xcd_remap = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_LOOKAHEAD")) e->lookahead = std::atoi(env) != 0;
+    if (const char* env = std::getenv("RSX_GRAPH")) e->use_graph = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_FOLD_PASTE")) e->fold_paste = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_SCAN_ZEROES")) e->scan_zeroes = std::atoi(env) != 0;
 
@@ -556,6 +632,7 @@ int rsx_destroy(rsx_engine* e)
         (void)hipEventDestroy(p.stop);
     }
     for (hipEvent_t ev : e->pool) (void)hipEventDestroy(ev);
+    for (const GraphEntry& g : e->graphs) (void)hipGraphExecDestroy(g.exec);
     for (int i = 0; i < 2; ++i) {
         if (e->keys[i] && hipFree(e->keys[i]) != hipSuccess) status = RSX_CLEANUP_FAILED;
         if (e->perm[i] && hipFree(e->perm[i]) != hipSuccess) status = RSX_CLEANUP_FAILED;
@@ -581,6 +658,8 @@ int rsx_set_stream(rsx_engine* e, void* hip_stream)
     if (bind_device(e, RSX_INITIALIZATION_FAILED) != RSX_OK) return RSX_INITIALIZATION_FAILED;
     const int rc = drain_events(e);
     if (rc != RSX_OK) return rc;
+    for (const GraphEntry& g : e->graphs) (void)hipGraphExecDestroy(g.exec);
+    e->graphs.clear();
     if (e->own_stream && e->stream) {
         RSX_TRY(hipStreamDestroy(e->stream), RSX_INITIALIZATION_FAILED);
     }
@@ -597,6 +676,7 @@ int rsx_set_option(rsx_engine* e, int option, int64_t value)
     case RSX_OPT_XCD_REMAP: e->xcd_remap = value != 0; return RSX_OK;
     case RSX_OPT_LOOKAHEAD: e->lookahead = value != 0; return RSX_OK;
     case RSX_OPT_REF_DIAGNOSTICS: e->ref_diag = value != 0; return RSX_OK;
+    case RSX_OPT_GRAPH: e->use_graph = value != 0; return RSX_OK;
     case RSX_OPT_FIRST_PASS:
         if (value < 0 || value > e->passes()) return fail(RSX_CALCULATION_FAILED, "rsx_set_option: first pass out of range");
         e->first_pass = static_cast<int>(value);

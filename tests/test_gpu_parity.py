@@ -437,3 +437,32 @@ def test_engine_reuse_and_concurrent_engines(mod, oracle):
         torch.cuda.synchronize()
         assert np.array_equal(e1.download(), np.sort(a))
         assert np.array_equal(e2.download(), np.sort(b))
+
+
+def test_graph_replay_small_sorts(mod, oracle):
+    """Sorts of <= 2^22 keys replay a captured hipGraph (RSX_OPT_GRAPH): same bytes as the eager
+    path, across repeated calls, changing inputs, both entry points and a payload."""
+    import torch
+    n = 200003
+    a = oracle.dataset("SeededUniform", "uint32", n, seed=1)
+    b = oracle.dataset("SeededUniform", "uint32", n, seed=2)
+    for graph in (1, 0):
+        with mod.Engine("uint32", n, payload=True) as e:
+            e.set_option(mod.OPT_GRAPH, graph)
+            for keys in (a, b, a):
+                e.upload(keys, np.arange(n, dtype=np.uint32))
+                e.sort()
+                ks, ps = e.download(want_perm=True)
+                assert np.array_equal(ks, np.sort(keys)) and np.array_equal(ps, np.argsort(keys, kind="stable").astype(np.uint32))
+            ta = torch.from_numpy(a.view(np.int32)).cuda()
+            tp = torch.arange(n, dtype=torch.int32, device="cuda")
+            e.set_stream(torch.cuda.current_stream().cuda_stream)
+            for _ in range(4):                      # alternates between the two internal buffers
+                e.sort_from(ta.data_ptr(), n, tp.data_ptr())
+            torch.cuda.synchronize()
+            ks, ps = e.download(want_perm=True)
+            assert np.array_equal(ks, np.sort(a)) and np.array_equal(ps, np.argsort(a, kind="stable").astype(np.uint32))
+            ta.copy_(torch.from_numpy(b.view(np.int32)).cuda())     # same pointer, new contents: the graph must not cache data
+            e.sort_from(ta.data_ptr(), n, tp.data_ptr())
+            torch.cuda.synchronize()
+            assert np.array_equal(e.download(), np.sort(b))
