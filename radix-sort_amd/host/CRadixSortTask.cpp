@@ -84,13 +84,7 @@ bool CRadixSortTask<T>::InitResources(hipc::Device Device, hipc::Context Context
     }
     hb.m_hResultFromGPU.resize(mNumberKeysRounded);
 
-    HostSpans<T> spans{
-        {hb.m_hKeys.data(), hb.m_hKeys.size()},
-        {hb.m_hHistograms.data(), hb.m_hHistograms.size()},
-        {hb.m_hGlobsum.data(), hb.m_hGlobsum.size()},
-        {hb.h_Permut.data(), hb.h_Permut.size()},
-        {hb.m_hResultFromGPU.data(), hb.m_hResultFromGPU.size()},
-    };
+    const HostSpans<T> spans = MakeHostSpans(hb);
     mRadixSortGPU.enablePermutation(mOptions.with_permutation);
     mRadixSortGPU.setStepwise(mOptions.stepwise);
     mRadixSortGPU.enablePinnedTransfers(mOptions.pinned);

@@ -1,7 +1,7 @@
-// CTestBase.h — the run sequence of one task, after the reference's
-// tests/CTestBase.{h,cpp}: InitResources -> ComputeCPU -> ComputeGPU -> ValidateResults ->
-// ReleaseResources.  Unlike the reference (tests/CTestBase.cpp:56-66, which returns true
-// even after printing "INVALID RESULTS!"), a failed validation fails the run.
+// CTestBase.h — drives one IComputeTask through its five calls in the order the reference's
+// harness uses (tests/CTestBase.cpp:20-67): resources, CPU referees, GPU sort, validation,
+// release.  One deliberate difference: the reference reports success even after it has printed
+// "INVALID RESULTS!" (tests/CTestBase.cpp:56-66); here a failed validation fails the run.
 #pragma once
 
 #include "Common/CommonDefs.h"
@@ -10,6 +10,7 @@
 
 #include <iostream>
 #include <string>
+#include <utility>
 #include <vector>
 
 class CTestBase {
@@ -19,28 +20,32 @@ public:
 
     virtual bool DoCompute() = 0;
 
-    virtual bool InitCLContext() { return m_computeState.init(); }   // name kept from the reference
+    /// Name kept from the reference; finds the HIP device.
+    virtual bool InitCLContext() { return m_computeState.init(); }
 
     virtual bool RunComputeTask(IComputeTask& Task, const LocalWorkSize& LocalWorkSize)
     {
-        if (!m_computeState.m_CLContext.valid()) {
-            std::cerr << "Error: RunComputeTask() cannot execute because the device context is null.\n";
+        const hipc::Context ctx = m_computeState.m_CLContext;
+        if (!ctx.valid()) {
+            std::cerr << "RunComputeTask: no device context (InitCLContext() not called or failed)\n";
             return false;
         }
-        if (!Task.InitResources(m_computeState.device(), m_computeState.m_CLContext)) {
-            std::cerr << "Error during resource allocation. Aborting execution." << std::endl;
-            Task.ReleaseResources();
+        struct Releaser {                      // ReleaseResources() on every exit path
+            IComputeTask& task;
+            ~Releaser() { task.ReleaseResources(); }
+        } releaser{Task};
+
+        if (!Task.InitResources(m_computeState.device(), ctx)) {
+            std::cerr << "RunComputeTask: resource allocation failed, task skipped\n";
             return false;
         }
-        std::cout << "Computing CPU reference result...";
+        std::cout << "[1/3] CPU referees (std::sort, RadixSortCPU) ... " << std::flush;
         Task.ComputeCPU();
-        std::cout << "DONE" << std::endl;
-        std::cout << "Computing GPU result..." << std::endl;
-        Task.ComputeGPU(m_computeState.m_CLContext, m_computeState.m_CLCommandQueue, LocalWorkSize);
-        std::cout << "DONE" << std::endl;
+        std::cout << "done\n[2/3] GPU sort" << std::endl;
+        Task.ComputeGPU(ctx, m_computeState.m_CLCommandQueue, LocalWorkSize);
+        std::cout << "[3/3] validation" << std::endl;
         const bool valid = Task.ValidateResults();
-        std::cout << (valid ? "GOLD TEST PASSED!\n" : "INVALID RESULTS!\n");
-        Task.ReleaseResources();
+        std::cout << (valid ? "GOLD TEST PASSED!" : "INVALID RESULTS!") << std::endl;
         return valid;
     }
 
