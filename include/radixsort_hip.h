@@ -65,6 +65,8 @@ typedef enum rsx_option {
                                  replayed; ignored while profiling and on the null stream.  Default 0: measured on
                                  MI355X the replay is no faster than eager launches (the ~3 us dependent-kernel
                                  boundary, not host launch cost, sets the 0.1 ms floor of a 33-kernel sort). */
+    RSX_OPT_SMALL_SCAN = 7,   /* 1 (default): inside rsx_sort, tables of at most 1024 tiles (2^22 keys) are scanned and
+                                 pasted by ONE workgroup in one launch instead of three; the step API is unaffected */
     RSX_OPT_LOOKAHEAD = 4     /* 1 (default): inside rsx_sort the reorder of pass p also counts pass p+1's digits per
                                  output tile, so only the first pass runs the histogram kernel; 0: every pass runs
                                  histogram -> scan -> paste -> reorder separately.  Results are identical. */

@@ -133,6 +133,7 @@ struct rsx_engine {
     int profile = 0;            // 0 off, 1 every launch, 2 reorder launches (+ whole sort) only
     int xcd_remap = 1;
     int lookahead = 1;          // rsx_sort builds pass p+1's histogram inside pass p's reorder
+    int small_scan = 1;         // rsx_sort: one-workgroup scan+paste for tables of <= 1024 tiles (env RSX_SMALL_SCAN)
     int fold_paste = 0;         // reorder adds globsum itself (no paste launch): measured 3 % slower, off; env RSX_FOLD_PASTE
     int scan_zeroes = 1;
     int first_pass = 0;
@@ -254,6 +255,26 @@ int launch_scan(rsx_engine* e, uint64_t count, bool from_counts = false)
     }
     RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
     return RSX_OK;
+}
+
+// rsx_sort only: tables of at most 1024 tiles (2^22 keys) are scanned AND pasted by one workgroup
+// in one launch.  Returns true when it took the pass (the caller then skips the paste).
+bool launch_scan_small(rsx_engine* e, uint64_t count, bool from_counts, int* rc)
+{
+    const uint32_t ntiles = static_cast<uint32_t>(e->ntiles(count));
+    if (!e->small_scan || count == 0 || ntiles > static_cast<uint32_t>(rsx::kSmallScanMaxTiles)) return false;
+    {
+        Bracket b(e, PH_SCAN);
+        if (from_counts && e->scan_zeroes) {
+            hipLaunchKernelGGL((rsx::scan_small_kernel<true, true>), dim3(1), dim3(rsx::kSmallScanThreads), 0, e->stream, e->table, e->counts_next, e->temp, ntiles);
+        } else if (from_counts) {
+            hipLaunchKernelGGL((rsx::scan_small_kernel<true, false>), dim3(1), dim3(rsx::kSmallScanThreads), 0, e->stream, e->table, e->counts_next, e->temp, ntiles);
+        } else {
+            hipLaunchKernelGGL((rsx::scan_small_kernel<false, false>), dim3(1), dim3(rsx::kSmallScanThreads), 0, e->stream, e->table, e->counts_next, e->temp, ntiles);
+        }
+    }
+    *rc = hipGetLastError() == hipSuccess ? RSX_OK : fail(RSX_CALCULATION_FAILED, "scan_small_kernel launch");
+    return true;
 }
 
 int launch_paste(rsx_engine* e, uint64_t count)
@@ -383,13 +404,15 @@ int sort_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext_
             // counted by the previous pass's reorder while it scattered (look-ahead)
             const bool first = pass == e->first_pass;
             rc = first ? launch_histogram<Key>(e, in, count, shift, RSX_RADIX - 1) : RSX_OK;
-            if (rc == RSX_OK) rc = launch_scan(e, count, /*from_counts=*/!first);
+            bool pasted = false;
+            if (rc == RSX_OK) pasted = launch_scan_small(e, count, /*from_counts=*/!first, &rc);
+            if (rc == RSX_OK && !pasted) rc = launch_scan(e, count, /*from_counts=*/!first);
             // PasteHistogram is folded into the reorder (it adds globsum[block] to the 16 table
             // entries it reads); only the last pass runs the paste kernel, so that the table a
             // caller downloads afterwards is the fully pasted one in either mode
             const bool last = pass + 1 == e->last_pass;
-            const bool fold = e->fold_paste && !last;
-            if (rc == RSX_OK && !fold) rc = launch_paste(e, count);
+            const bool fold = e->fold_paste && !last && !pasted;
+            if (rc == RSX_OK && !fold && !pasted) rc = launch_paste(e, count);
             const int next_shift = last ? -1 : shift + RSX_RADIX_BITS;
             if (rc == RSX_OK && !last && !e->scan_zeroes) {
                 if (hipMemsetAsync(e->counts_next, 0, static_cast<size_t>(e->ntiles(count)) * RSX_RADIX * 4, e->stream) != hipSuccess) rc = RSX_CALCULATION_FAILED;
@@ -548,6 +571,7 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
     if (const char* env = std::getenv("RSX_XCD_REMAP")) e->xcd_remap = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_LOOKAHEAD")) e->lookahead = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_GRAPH")) e->use_graph = std::atoi(env) != 0;
+    if (const char* env = std::getenv("RSX_SMALL_SCAN")) e->small_scan = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_FOLD_PASTE")) e->fold_paste = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_SCAN_ZEROES")) e->scan_zeroes = std::atoi(env) != 0;
 
@@ -677,6 +701,7 @@ int rsx_set_option(rsx_engine* e, int option, int64_t value)
     case RSX_OPT_LOOKAHEAD: e->lookahead = value != 0; return RSX_OK;
     case RSX_OPT_REF_DIAGNOSTICS: e->ref_diag = value != 0; return RSX_OK;
     case RSX_OPT_GRAPH: e->use_graph = value != 0; return RSX_OK;
+    case RSX_OPT_SMALL_SCAN: e->small_scan = value != 0; return RSX_OK;
     case RSX_OPT_FIRST_PASS:
         if (value < 0 || value > e->passes()) return fail(RSX_CALCULATION_FAILED, "rsx_set_option: first pass out of range");
         e->first_pass = static_cast<int>(value);

@@ -343,6 +343,120 @@ __global__ __launch_bounds__(kScanTiles) void paste_kernel(uint32_t* __restrict_
     }
 }
 
+// Whole table scan in ONE workgroup — scan #1, scan #2 and paste of a small table in a single
+// launch.  Up to 2^22 keys a pass is so short that the three tiny kernels above and their launch
+// boundaries (~15 us together) dominate it; one 1024-thread workgroup walks a table of at most
+// 1024 tiles in a few microseconds (measured: 0.081 vs 0.107 ms per sort at 2^16 keys, 0.098 vs
+// 0.126 at 2^20; beyond 2^22 keys the single workgroup loses to the three launches).  Thread t owns the consecutive tiles
+// [t*tpt, (t+1)*tpt): it sums its rows per digit, the 16 per-digit sums are scanned across the
+// workgroup, digit d starts after all keys of smaller digits, and a second walk over the same
+// rows writes the global exclusive prefix.
+constexpr int kSmallScanThreads = 1024;
+constexpr int kSmallScanMaxTiles = 1024;   // one tile per thread; beyond ~2^22 keys one workgroup is slower than the three launches
+
+template <bool FROM_COUNTS, bool ZERO_BACK>
+__global__ __launch_bounds__(kSmallScanThreads) void scan_small_kernel(uint32_t* __restrict__ table, uint32_t* __restrict__ counts,
+                                                                        uint32_t* __restrict__ temp, uint32_t ntiles)
+{
+    constexpr int WAVES = kSmallScanThreads / kWave;
+    __shared__ uint32_t wsum[WAVES][kRadix], wpre[WAVES][kRadix], dtot[kRadix];
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    const uint32_t tpt = (ntiles + kSmallScanThreads - 1) / kSmallScanThreads;
+    const uint32_t t0 = tid * tpt;
+    const uint32_t t1 = (t0 + tpt < ntiles) ? t0 + tpt : ntiles;
+
+    auto load_row = [&](uint32_t tile, uint32_t (&c)[kRadix]) {
+        if constexpr (FROM_COUNTS) {
+            const U32x4* row = reinterpret_cast<const U32x4*>(counts + static_cast<uint64_t>(tile) * kRadix);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const U32x4 x = row[q];
+                c[q * 4 + 0] = x.v[0];
+                c[q * 4 + 1] = x.v[1];
+                c[q * 4 + 2] = x.v[2];
+                c[q * 4 + 3] = x.v[3];
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < kRadix; ++d) {
+                c[d] = table[static_cast<uint64_t>(d) * ntiles + tile];
+            }
+        }
+    };
+
+    uint32_t sums[kRadix];
+#pragma unroll
+    for (int d = 0; d < kRadix; ++d) {
+        sums[d] = 0;
+    }
+    for (uint32_t tile = t0; tile < t1; ++tile) {
+        uint32_t c[kRadix];
+        load_row(tile, c);
+#pragma unroll
+        for (int d = 0; d < kRadix; ++d) {
+            sums[d] += c[d];
+        }
+    }
+    uint32_t start[kRadix];
+#pragma unroll
+    for (int d = 0; d < kRadix; ++d) {
+        start[d] = wave_inclusive_scan(sums[d]);
+    }
+    if (lane == kWave - 1) {
+#pragma unroll
+        for (int d = 0; d < kRadix; ++d) {
+            wsum[wave][d] = start[d];
+        }
+    }
+    __syncthreads();
+    // cross-wave combine by 256 threads (wave w, digit d): sums of the waves before w; kept out
+    // of registers on purpose (16 x 16 values per thread would spill)
+    if (tid < WAVES * kRadix) {
+        const uint32_t w = tid / kRadix, d = tid % kRadix;
+        uint32_t acc = 0;
+#pragma unroll 1
+        for (uint32_t w2 = 0; w2 < w; ++w2) {
+            acc += wsum[w2][d];
+        }
+        wpre[w][d] = acc;
+        if (w == WAVES - 1) {
+            dtot[d] = acc + wsum[w][d];
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;             // keys with a smaller digit, whole array
+#pragma unroll 1
+        for (int d = 0; d < kRadix; ++d) {
+            const uint32_t t = dtot[d];
+            dtot[d] = run;
+            run += t;
+        }
+        temp[0] = run;                // grand total, as scan #2 leaves it
+    }
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < kRadix; ++d) {
+        start[d] = dtot[d] + wpre[wave][d] + start[d] - sums[d];
+    }
+    for (uint32_t tile = t0; tile < t1; ++tile) {
+        uint32_t c[kRadix];
+        load_row(tile, c);
+        if constexpr (FROM_COUNTS && ZERO_BACK) {
+            U32x4* row = reinterpret_cast<U32x4*>(counts + static_cast<uint64_t>(tile) * kRadix);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                row[q] = U32x4{{0u, 0u, 0u, 0u}};
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < kRadix; ++d) {
+            table[static_cast<uint64_t>(d) * ntiles + tile] = start[d];
+            start[d] += c[d];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // reorder: the stable scatter (the graded pass)
 // ---------------------------------------------------------------------------

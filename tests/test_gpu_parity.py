@@ -190,15 +190,17 @@ def test_lookahead_histogram_equals_separate_histogram_passes(mod, oracle, dt, n
     keys = oracle.dataset(kind, dt, n)
     perm = np.arange(n, dtype=np.uint32) if payload else None
     outs = []
-    for la in (0, 1):
+    for la, small in ((0, 0), (1, 1), (1, 0), (0, 1)):
         with mod.Engine(dt, n, payload=payload) as e:
             e.set_option(mod.OPT_LOOKAHEAD, la)
+            e.set_option(mod.OPT_SMALL_SCAN, small)
             e.upload(keys, perm)
             e.sort()
             ntab = 16 * e.geometry().num_tiles
             outs.append(e.download(want_perm=payload, hist_cap=ntab))
-    for a, b in zip(outs[0], outs[1]):
-        assert np.array_equal(a, b)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert np.array_equal(a, b)
     assert np.array_equal(outs[1][0], np.sort(keys))
     if payload:
         assert np.array_equal(outs[1][1], np.argsort(keys, kind="stable").astype(np.uint32))
@@ -270,7 +272,14 @@ def test_timings_profile_mode(mod, oracle):
         e.upload(keys)
         e.sort()
         t = e.timings(reset=True)
-        assert t.histogram.n == 1 and t.reorder.n == 8 and t.paste.n == 8      # look-ahead: one histogram launch
+        # look-ahead: one histogram launch; 256 tiles: the one-workgroup scan does scan+paste in one launch per pass
+        assert t.histogram.n == 1 and t.reorder.n == 8 and t.paste.n == 0 and t.scan.n == 8
+        assert np.array_equal(e.download(), np.sort(keys))
+        e.set_option(mod.OPT_SMALL_SCAN, 0)
+        e.upload(keys)
+        e.sort()
+        t = e.timings(reset=True)
+        assert t.histogram.n == 1 and t.reorder.n == 8 and t.paste.n == 8      # three-kernel scan
         assert t.scan.n == 16
         assert np.array_equal(e.download(), np.sort(keys))
         e.set_option(mod.OPT_LOOKAHEAD, 0)
