@@ -54,7 +54,7 @@ def torch_view(t_np: np.ndarray):
     return torch.from_numpy(t_np.view(signed) if signed else t_np)
 
 
-def cpu_baseline(sample: np.ndarray) -> dict:
+def cpu_baseline(sample: np.ndarray, whole: bool) -> dict:
     """Reference oracle timed like SortDataRadix (copy-in + sort), 1 thread (checker only)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from _oracle import Oracle, RefOracle
@@ -64,7 +64,7 @@ def cpu_baseline(sample: np.ndarray) -> dict:
         ms, kind = Oracle().time_radix_sort(sample, iters=1), "port"
     return {
         "value": round(sample.size / ms * 1e-3, 3), "unit": "Mkeys/s", "cores": 1, "kind": kind,
-        "sample": f"first 2^{int(np.log2(sample.size))} keys of the same input, 1 iteration of copy-in + RadixSortCPU "
+        "sample": f"first 2^{int(np.log2(sample.size))} keys of the same input ({'the whole workload' if whole else 'a prefix'}), 1 iteration of copy-in + RadixSortCPU "
                   f"({ms:.0f} ms); host has {os.cpu_count()} logical cores",
     }
 
@@ -88,7 +88,8 @@ def main() -> None:
     ap.add_argument("--dtype", default="uint32", choices=list(DTYPE_CODES))
     ap.add_argument("--payload", action="store_true", help="carry a uint32 payload (h_Permut)")
     ap.add_argument("--dataset", default="Random", choices=list(KIND_CODES))
-    ap.add_argument("--cpu-sample-log2", type=int, default=26)
+    ap.add_argument("--total-log2-keys", type=int, default=None, help="total keys over all GPUs = 2^this (e.g. 30 for BASELINE config 4); overrides --log2-keys")
+    ap.add_argument("--cpu-sample-log2", type=int, default=28, help="CPU baseline sample = first 2^this keys of the input (2^28 ~ 13 s of RadixSortCPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="no HIP events inside the timed region (roofline then comes from the instrumented steps after it)")
@@ -114,7 +115,12 @@ def main() -> None:
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
-    n = 1 << args.log2_keys
+    if args.total_log2_keys is not None:
+        if (1 << args.total_log2_keys) % world:
+            raise SystemExit("--total-log2-keys: total must divide evenly over the ranks")
+        n = (1 << args.total_log2_keys) // world
+    else:
+        n = 1 << args.log2_keys
     key_bytes = np.dtype(args.dtype).itemsize
     pay_bytes = 4 if args.payload else 0
     # N=1: the reference's Random generator.  N>1: independent per-rank streams of the
@@ -195,7 +201,8 @@ def main() -> None:
     # with N>1 the partition pass and the local passes see ~n keys each
     scatter_bytes = 2.0 * n_local * (key_bytes + pay_bytes)
     achieved = scatter_bytes / (reorder_ms * 1e-3) * 1e-9 if reorder_ms > 0 else 0.0
-    workload = f"2^{args.log2_keys} {args.dtype}{'+u32 payload' if args.payload else ''} {kind}, 4-bit digits, {key_bytes * 2} passes"
+    lg = n.bit_length() - 1 if n & (n - 1) == 0 else None
+    workload = f"{'2^%d' % lg if lg is not None else n} {args.dtype}{'+u32 payload' if args.payload else ''} {kind}, 4-bit digits, {key_bytes * 2} passes"
     line = {
         "metric": "Mkeys/s + scatter-pass HBM GB/s (% of peak), 2^28 uint32 keys",
         "value": round(total_keys / (elapsed / args.steps) * 1e-6, 1),
@@ -219,7 +226,8 @@ def main() -> None:
                                  "note": "fully instrumented steps after the timed region"},
     }
     if rank == 0 and not sharded and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(host_keys[: 1 << min(args.cpu_sample_log2, args.log2_keys)])
+        m = min(1 << args.cpu_sample_log2, n)
+        line["cpu_baseline"] = cpu_baseline(host_keys[:m], whole=(m == n))
     if rank == 0:
         print(json.dumps(line), flush=True)
     eng.close()
