@@ -35,9 +35,11 @@ def sort_case(draw):
         keys = rng.choice(np.array([info.min, info.min + 1, 0, 1, info.max - 1, info.max], dtype=dt), size=n)
     elif shape == "low_bits":
         keys = rng.integers(0, 16, size=n).astype(dt)                       # only the first pass does anything
-    else:
-        keys = (rng.integers(0, 16, size=n).astype(np.uint64) << np.uint64(info.bits - 4)).astype(np.uint64).view(np.uint64).astype(dt) \\
-            if dt.startswith("u") else (rng.integers(-8, 8, size=n).astype(np.int64) << (info.bits - 4)).astype(dt)
+    else:                                                                    # only the last pass does anything
+        if dt.startswith("u"):
+            keys = (rng.integers(0, 16, size=n).astype(np.uint64) << np.uint64(info.bits - 4)).astype(dt)
+        else:
+            keys = (rng.integers(-8, 8, size=n).astype(np.int64) << (info.bits - 4)).astype(dt)
     return dt, keys, draw(st.booleans()), draw(st.booleans())
 
 
