@@ -21,8 +21,9 @@ def sort_case(draw):
     if shape == "full":
         keys = rng.integers(info.min, info.max, size=n, dtype=dt, endpoint=True)
     elif shape == "narrow":
-        lo = int(rng.integers(info.min, info.max - 1000, dtype=np.int64 if dt != "uint64" else np.uint64))
-        keys = (lo + rng.integers(0, 1000, size=n)).astype(dt)
+        span = int(info.max) - int(info.min) - 2000
+        lo = int(info.min) + (int(rng.integers(0, 1 << 20)) * span >> 20)          # python ints: no overflow
+        keys = np.array([lo + int(v) for v in rng.integers(0, 1000, size=n)], dtype=dt)
     elif shape == "ties":
         keys = rng.integers(0, 7, size=n).astype(dt)
     elif shape == "sorted":
@@ -30,7 +31,7 @@ def sort_case(draw):
     elif shape == "reverse":
         keys = np.sort(rng.integers(info.min, info.max, size=n, dtype=dt, endpoint=True))[::-1].copy()
     elif shape == "constant":
-        keys = np.full(n, rng.integers(info.min, info.max, dtype=dt, endpoint=True), dtype=dt)
+        keys = np.full(n, int(rng.integers(info.min, info.max, dtype=dt, endpoint=True)), dtype=dt)
     elif shape == "extremes":
         keys = rng.choice(np.array([info.min, info.min + 1, 0, 1, info.max - 1, info.max], dtype=dt), size=n)
     elif shape == "low_bits":
