@@ -182,6 +182,13 @@ int rsx_partition(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, 
  *   bucket = min(mul ? mulhi(x, mul) : x >> shift, 15), mul = floor(16 * 2^keybits / (hi - lo + 1)):
  *   16 equal-width buckets over [lo, hi] (mul == 0 for ranges of at most 16 values);
  *   bucket_offsets receives 17 entries. */
+/* The same bit-field partition in two halves, so that the host can look at the bucket sizes (and
+ * exchange them between ranks) BEFORE anything is moved: rsx_partition_count runs the histogram
+ * and returns the (1<<bits) bucket sizes (synchronises); rsx_partition_scatter must follow on the
+ * same keys / n / bit field and does scan + paste + reorder into the caller's buffers (asynchronous). */
+int rsx_partition_count(rsx_engine* e, const void* d_keys, uint64_t n, int shift, int bits, uint64_t* bucket_counts);
+int rsx_partition_scatter(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n, int shift, int bits,
+                          void* d_keys_out, uint32_t* d_payload_out);
 int rsx_key_range(rsx_engine* e, const void* d_keys, uint64_t n, uint64_t* lo, uint64_t* hi);
 int rsx_partition_range(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n, uint64_t lo, int shift, uint64_t mul,
                         void* d_keys_out, uint32_t* d_payload_out, uint64_t* bucket_offsets);

@@ -38,7 +38,7 @@ SYMBOLS = [
     "rsx_create", "rsx_destroy", "rsx_set_stream", "rsx_set_option", "rsx_get_geometry", "rsx_resize",
     "rsx_upload", "rsx_fill_pad", "rsx_download", "rsx_pin_host", "rsx_unpin_host",
     "rsx_histogram", "rsx_scan", "rsx_paste", "rsx_reorder", "rsx_sort", "rsx_sync",
-    "rsx_sort_from", "rsx_partition", "rsx_key_range", "rsx_partition_range", "rsx_result_device", "rsx_copy_result", "rsx_timings",
+    "rsx_sort_from", "rsx_partition", "rsx_partition_count", "rsx_partition_scatter", "rsx_key_range", "rsx_partition_range", "rsx_result_device", "rsx_copy_result", "rsx_timings",
 ]
 
 
@@ -126,6 +126,8 @@ def load_library() -> C.CDLL:
         "rsx_sync": ([P], I),
         "rsx_sort_from": ([P, P, P, U64], I),
         "rsx_partition": ([P, P, P, U64, I, I, P, P, C.POINTER(U64)], I),
+        "rsx_partition_count": ([P, P, U64, I, I, C.POINTER(U64)], I),
+        "rsx_partition_scatter": ([P, P, P, U64, I, I, P, P], I),
         "rsx_key_range": ([P, P, U64, C.POINTER(U64), C.POINTER(U64)], I),
         "rsx_partition_range": ([P, P, P, U64, U64, I, U64, P, P, C.POINTER(U64)], I),
         "rsx_result_device": ([P, C.POINTER(P), C.POINTER(P)], I),
@@ -276,6 +278,17 @@ class Engine:
             self._h, C.c_void_p(d_keys), C.c_void_p(d_payload) if d_payload else None, n, shift, bits,
             C.c_void_p(d_keys_out), C.c_void_p(d_payload_out) if d_payload_out else None, offs), "rsx_partition")
         return [int(v) for v in offs]
+
+    def partition_count(self, d_keys: int, n: int, shift: int, bits: int) -> list[int]:
+        counts = (C.c_uint64 * (1 << bits))()
+        self._check(self.lib.rsx_partition_count(self._h, C.c_void_p(d_keys), n, shift, bits, counts), "rsx_partition_count")
+        return [int(v) for v in counts]
+
+    def partition_scatter(self, d_keys: int, n: int, shift: int, bits: int, d_keys_out: int,
+                          d_payload: int | None = None, d_payload_out: int | None = None) -> None:
+        self._check(self.lib.rsx_partition_scatter(
+            self._h, C.c_void_p(d_keys), C.c_void_p(d_payload) if d_payload else None, n, shift, bits,
+            C.c_void_p(d_keys_out), C.c_void_p(d_payload_out) if d_payload_out else None), "rsx_partition_scatter")
 
     def key_range(self, d_keys: int, n: int) -> tuple[int, int]:
         lo, hi = C.c_uint64(), C.c_uint64()

@@ -118,6 +118,9 @@ struct rsx_engine {
     uint32_t* counts_next = nullptr;            // look-ahead histogram of the next pass, [tile][digit]
     uint32_t* ref_table = nullptr;              // diagnostics in the reference's [digit][group][item] geometry
     uint32_t* ref_globsum = nullptr;
+    const void* counted_keys = nullptr;         // rsx_partition_count left a raw table for exactly this input
+    uint64_t counted_n = 0;
+    int counted_shift = 0, counted_bits = 0;
     const void* last_in = nullptr;              // input buffer and shift of the most recent reorder
     int last_shift = 0;
     int ref_diag = 0;                           // RSX_OPT_REF_DIAGNOSTICS
@@ -951,6 +954,53 @@ int rsx_partition(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, 
     for (uint32_t d = 0; d < buckets; ++d) bucket_offsets[d] = e->starts_host[d];
     bucket_offsets[buckets] = n;
     return RSX_OK;
+}
+
+int rsx_partition_count(rsx_engine* e, const void* d_keys, uint64_t n, int shift, int bits, uint64_t* bucket_counts)
+{
+    if (!e || !bucket_counts) return fail(RSX_CALCULATION_FAILED, "rsx_partition_count: null argument");
+    if (bits < 0 || bits > RSX_RADIX_BITS || shift < 0 || shift + bits > e->key_bytes * 8)
+        return fail(RSX_CALCULATION_FAILED, "rsx_partition_count: bit field out of range (at most 4 bits)");
+    if (n > e->capacity) return fail(RSX_RESIZE_FAILED, "rsx_partition_count: beyond capacity");
+    const uint32_t buckets = 1u << bits;
+    for (uint32_t d = 0; d < buckets; ++d) bucket_counts[d] = 0;
+    if (n == 0) return RSX_OK;
+    if (!d_keys || !aligned16(d_keys)) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_partition_count: keys must be a 16-byte aligned device pointer");
+    if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
+    const int rc = RSX_BY_KEY(e, launch_histogram<uint32_t>(e, d_keys, n, shift, buckets - 1), launch_histogram<uint64_t>(e, d_keys, n, shift, buckets - 1));
+    if (rc != RSX_OK) return rc;
+    hipLaunchKernelGGL(rsx::digit_totals_kernel, dim3(RSX_RADIX), dim3(256), 0, e->stream, e->table, static_cast<uint32_t>(e->ntiles(n)), e->range_dev);
+    RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
+    RSX_TRY(hipMemcpyAsync(e->range_host, e->range_dev, RSX_RADIX * 8, hipMemcpyDeviceToHost, e->stream), RSX_CALCULATION_FAILED);
+    RSX_TRY(hipStreamSynchronize(e->stream), RSX_CALCULATION_FAILED);
+    for (uint32_t d = 0; d < buckets; ++d) bucket_counts[d] = e->range_host[d];
+    e->counted_keys = d_keys;
+    e->counted_n = n;
+    e->counted_shift = shift;
+    e->counted_bits = bits;
+    return RSX_OK;
+}
+
+int rsx_partition_scatter(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n, int shift, int bits,
+                          void* d_keys_out, uint32_t* d_payload_out)
+{
+    if (!e) return fail(RSX_CALCULATION_FAILED, "rsx_partition_scatter: null engine");
+    if (d_keys != e->counted_keys || n != e->counted_n || shift != e->counted_shift || bits != e->counted_bits)
+        return fail(RSX_CALCULATION_FAILED, "rsx_partition_scatter: must follow rsx_partition_count on the same keys and bit field");
+    e->counted_keys = nullptr;       // the table is consumed by this call
+    if (n == 0) return RSX_OK;
+    if (!d_keys_out || !aligned16(d_keys_out)) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_partition_scatter: output must be a 16-byte aligned device pointer");
+    const bool with_payload = e->has_payload && d_payload && d_payload_out;
+    if (e->has_payload && !with_payload) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_partition_scatter: payload engine needs payload buffers");
+    if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
+    int rc = launch_scan(e, n);
+    if (rc == RSX_OK) rc = launch_paste(e, n);
+    if (rc != RSX_OK) return rc;
+    const uint32_t mask = (1u << bits) - 1;
+    const uint32_t* pin = with_payload ? d_payload : nullptr;
+    uint32_t* pout = with_payload ? d_payload_out : nullptr;
+    return RSX_BY_KEY(e, launch_reorder<uint32_t>(e, d_keys, d_keys_out, pin, pout, n, shift, mask),
+                      launch_reorder<uint64_t>(e, d_keys, d_keys_out, pin, pout, n, shift, mask));
 }
 
 int rsx_key_range(rsx_engine* e, const void* d_keys, uint64_t n, uint64_t* lo, uint64_t* hi)

@@ -966,6 +966,28 @@ __global__ void fill_kernel(Key* __restrict__ dst, uint64_t first, uint64_t coun
     }
 }
 
+// per-digit totals of a RAW counter table: out[d] = sum over tiles of table[d][tile] (one workgroup per digit)
+__global__ __launch_bounds__(256) void digit_totals_kernel(const uint32_t* __restrict__ table, uint32_t ntiles, unsigned long long* __restrict__ out)
+{
+    __shared__ unsigned long long wsum[256 / kWave];
+    const uint32_t d = blockIdx.x;
+    unsigned long long acc = 0;
+    for (uint32_t t = threadIdx.x; t < ntiles; t += blockDim.x) {
+        acc += table[static_cast<uint64_t>(d) * ntiles + t];
+    }
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        acc += __shfl_xor(acc, off);
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        wsum[threadIdx.x / kWave] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[d] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    }
+}
+
 // bucket start offsets of a finished (scanned + pasted) table: out[d] = table[d][0]
 __global__ void bucket_starts_kernel(const uint32_t* __restrict__ table, uint32_t ntiles, uint32_t* __restrict__ out)
 {

@@ -5,6 +5,12 @@ The reference has no multi-device path ("Parallelism strategies: non
 is the capability the north-star adds.  LSD passes are not independent
 across shards, but a most-significant-bits partition is, so the data path is:
 
+  Fast path (keys that use their whole bit range, e.g. uniform random): every rank counts its
+  keys by the top 4 key bits (`rsx_partition_count`), the counts are exchanged, and if dealing
+  those 16 buckets out leaves no rank with more than 1.25x its share, the keys are grouped by
+  those bits (`rsx_partition_scatter`) and exchanged — one read less and two host syncs fewer
+  than the general path, which is otherwise:
+
   0. every rank finds the min and max of its keys (`rsx_key_range`, one read) and the ranks
      agree on the global range [lo, hi] (`all_gather` of 4 words).  If lo == hi all keys are
      equal and nothing needs to move;
@@ -116,6 +122,29 @@ def balanced_owner(global_counts: list[int], world_size: int) -> list[int]:
     return owner
 
 
+def gather_counts(counts: list[int], world_size: int, dist, device) -> list[list[int]]:
+    """[source rank][bucket] table of everybody's 16 bucket counts (one all_gather)."""
+    if dist is None:
+        return [list(counts)]
+    import torch
+
+    t = torch.tensor(counts, dtype=torch.int64, device=device)
+    gathered = torch.empty(world_size * RADIX, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(gathered, t)
+    return gathered.cpu().view(world_size, RADIX).tolist()
+
+
+def plan_from_table(table: list[list[int]], rank: int, world_size: int) -> tuple[ExchangePlan, float]:
+    """Exchange plan from the gathered count table plus the resulting imbalance
+    (largest rank load / ideal load)."""
+    totals = [sum(row[b] for row in table) for b in range(RADIX)]
+    owner = balanced_owner(totals, world_size)
+    sends = [[sum(row[b] for b in range(RADIX) if owner[b] == dst) for dst in range(world_size)] for row in table]
+    loads = [sum(s[dst] for s in sends) for dst in range(world_size)]
+    ideal = max(1.0, sum(totals) / world_size)
+    return ExchangePlan(send=sends[rank], recv=recv_splits(sends, rank)), max(loads) / ideal
+
+
 def plan_exchange(bucket_offsets: list[int], rank: int, world_size: int, dist, device) -> ExchangePlan:
     """Step 2 of the module docstring ("histogram all-to-all"): all ranks learn every rank's 16
     bucket counts, deal the buckets to ranks in balanced contiguous ranges, and derive their
@@ -147,6 +176,7 @@ class ShardedSorter:
         # force_exchange: run partition -> all_gather -> all_to_all even with one rank (the
         # collectives then talk to self); lets a 1-GPU box exercise the real RCCL call path
         self.force_exchange = force_exchange and dist is not None
+        self.max_imbalance = 1.25      # top-bit buckets are used when no rank would get more than this x its share
         if world_size > 1 and dist is None:
             raise ValueError("a torch.distributed module is required for world_size > 1")
 
@@ -159,6 +189,16 @@ class ShardedSorter:
         if self.world == 1 and not self.force_exchange:
             self.engine.sort_from(keys.data_ptr(), n, payload.data_ptr() if payload is not None else None)
             return n
+        # fast path: buckets on the top 4 key bits, if they deal out evenly
+        top_shift = self.key_bits - PARTITION_BITS
+        table = gather_counts(self.engine.partition_count(keys.data_ptr(), n, top_shift, PARTITION_BITS), self.world, self.dist, keys.device)
+        plan, imbalance = plan_from_table(table, self.rank, self.world)
+        if imbalance <= self.max_imbalance:
+            self.engine.partition_scatter(
+                keys.data_ptr(), n, top_shift, PARTITION_BITS, staging.data_ptr(),
+                payload.data_ptr() if payload is not None else None,
+                staging_payload.data_ptr() if staging_payload is not None else None)
+            return self._exchange_and_sort(plan, n, staging, recv, payload, staging_payload, recv_payload)
         lo, hi = self.engine.key_range(keys.data_ptr(), n)
         lo, hi = global_key_range(lo, hi, self.world, self.dist, keys.device)
         if lo >= hi:
@@ -172,6 +212,9 @@ class ShardedSorter:
             payload.data_ptr() if payload is not None else None,
             staging_payload.data_ptr() if staging_payload is not None else None)
         plan = plan_exchange(offs, self.rank, self.world, self.dist, keys.device)
+        return self._exchange_and_sort(plan, n, staging, recv, payload, staging_payload, recv_payload)
+
+    def _exchange_and_sort(self, plan, n, staging, recv, payload, staging_payload, recv_payload):
         if plan.n_recv > recv.numel():
             raise RuntimeError(f"rank {self.rank}: receives {plan.n_recv} keys but the receive buffer holds {recv.numel()}")
         self.dist.all_to_all_single(recv[:plan.n_recv], staging[:n], plan.recv, plan.send)

@@ -88,6 +88,16 @@ class _CpuEngineDouble:
             u = u ^ u.dtype.type(1 << (self.dtype.itemsize * 8 - 1))
         return u
 
+    def partition_count(self, d_keys, n, shift, bits):
+        u = self._biased(self._view(d_keys, n, self.dtype))
+        d = ((u >> u.dtype.type(shift)) & u.dtype.type((1 << bits) - 1)).astype(np.int64)
+        self._counted = (d_keys, n, shift, bits)
+        return [int(v) for v in np.bincount(d, minlength=1 << bits)]
+
+    def partition_scatter(self, d_keys, n, shift, bits, d_keys_out, d_payload=None, d_payload_out=None):
+        assert self._counted == (d_keys, n, shift, bits)
+        self.partition(d_keys, n, shift, bits, d_keys_out, d_payload, d_payload_out)
+
     def key_range(self, d_keys, n):
         if n == 0:
             return (1 << 64) - 1, 0

@@ -155,3 +155,22 @@ def test_key_range_and_ranged_partition(rsx, oracle, dt):
     assert np.array_equal(got, keys[np.argsort(d, kind="stable")])
     assert offs == [0] + [int(v) for v in np.cumsum(np.bincount(d, minlength=16))]
     assert min(np.diff(offs)) > 0                      # all 16 buckets used: the range is covered evenly
+
+
+def test_partition_count_then_scatter(rsx, oracle):
+    """The two-call bit-field partition: counts first (host decides), scatter afterwards."""
+    import torch
+    n = 123457
+    keys = oracle.dataset("SeededUniform", "int32", n)
+    tk = torch.from_numpy(keys).cuda()
+    out = torch.empty_like(tk)
+    u = keys.view(np.uint32) ^ np.uint32(1 << 31)
+    d = (u >> np.uint32(28)).astype(np.int64)
+    with rsx.Engine("int32", n) as e:
+        e.set_stream(torch.cuda.current_stream().cuda_stream)
+        assert e.partition_count(tk.data_ptr(), n, 28, 4) == [int(v) for v in np.bincount(d, minlength=16)]
+        e.partition_scatter(tk.data_ptr(), n, 28, 4, out.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), keys[np.argsort(d, kind="stable")])
+        with pytest.raises(rsx.RadixSortError):          # the table was consumed
+            e.partition_scatter(tk.data_ptr(), n, 28, 4, out.data_ptr())
