@@ -410,9 +410,9 @@ int sort_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext_
             bool pasted = false;
             if (rc == RSX_OK) pasted = launch_scan_small(e, count, /*from_counts=*/!first, &rc);
             if (rc == RSX_OK && !pasted) rc = launch_scan(e, count, /*from_counts=*/!first);
-            // PasteHistogram is folded into the reorder (it adds globsum[block] to the 16 table
-            // entries it reads); only the last pass runs the paste kernel, so that the table a
-            // caller downloads afterwards is the fully pasted one in either mode
+            // small tables were scanned and pasted in one launch; otherwise the paste kernel runs
+            // (RSX_FOLD_PASTE=1 lets the reorder add globsum[group] itself instead — measured slower;
+            // the last pass always pastes so that a downloaded table is the global prefix in any mode)
             const bool last = pass + 1 == e->last_pass;
             const bool fold = e->fold_paste && !last && !pasted;
             if (rc == RSX_OK && !fold && !pasted) rc = launch_paste(e, count);
@@ -455,7 +455,7 @@ int sort_chain(rsx_engine* e, const void* ext_keys, const uint32_t* ext_perm, ui
     key.cur = e->cur;
     key.first = e->first_pass;
     key.last = e->last_pass;
-    key.flags = (e->lookahead ? 1 : 0) | (e->xcd_remap ? 2 : 0) | (e->fold_paste ? 4 : 0) | (e->scan_zeroes ? 8 : 0);
+    key.flags = (e->lookahead ? 1 : 0) | (e->xcd_remap ? 2 : 0) | (e->fold_paste ? 4 : 0) | (e->scan_zeroes ? 8 : 0) | (e->small_scan ? 16 : 0);
     key.stream = e->stream;
     for (const GraphEntry& g : e->graphs) {
         if (g.in == key.in && g.pin == key.pin && g.n == key.n && g.cur == key.cur && g.first == key.first && g.last == key.last &&
