@@ -1,0 +1,50 @@
+"""Soak run: many sorts of random shape on one engine per (dtype, payload), every result checked
+against numpy's stable sort.  python tools/soak.py [iterations] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as entry
+
+m = entry.load_package()
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
+cap = 3_000_000
+engines = {(dt, p): m.Engine(dt, cap, payload=p) for dt in ("uint32", "int32", "uint64", "int64") for p in (False, True)}
+t0 = time.time()
+for it in range(iters):
+    dt = ("uint32", "int32", "uint64", "int64")[rng.integers(0, 4)]
+    payload = bool(rng.integers(0, 2))
+    n = int(rng.integers(1, cap)) if rng.integers(0, 4) else int(rng.integers(1, 9000))
+    info = np.iinfo(dt)
+    shape = rng.integers(0, 5)
+    if shape == 0:
+        keys = rng.integers(info.min, info.max, size=n, dtype=dt, endpoint=True)
+    elif shape == 1:
+        keys = rng.integers(0, 100, size=n).astype(dt)
+    elif shape == 2:
+        keys = np.sort(rng.integers(info.min, info.max, size=n, dtype=dt, endpoint=True))
+    elif shape == 3:
+        keys = np.full(n, int(rng.integers(0, 1000)), dtype=dt)
+    else:
+        keys = (rng.integers(0, 1 << 16, size=n).astype(np.int64) * 65537 % 1000003).astype(dt)
+    e = engines[(dt, payload)]
+    e.set_option(m.OPT_LOOKAHEAD, int(rng.integers(0, 2)))
+    e.set_option(m.OPT_SMALL_SCAN, int(rng.integers(0, 2)))
+    perm = np.arange(n, dtype=np.uint32) if payload else None
+    e.upload(keys, perm)
+    e.sort()
+    if payload:
+        ks, ps = e.download(want_perm=True)
+        ok = np.array_equal(ks, np.sort(keys, kind="stable")) and np.array_equal(ps, np.argsort(keys, kind="stable").astype(np.uint32))
+    else:
+        ok = np.array_equal(e.download(), np.sort(keys, kind="stable"))
+    if not ok:
+        print("MISMATCH", it, dt, payload, n, shape, flush=True)
+        sys.exit(1)
+    if it % 50 == 0:
+        print(f"iter {it} ok ({time.time() - t0:.0f} s)", flush=True)
+print(f"soak ok: {iters} sorts in {time.time() - t0:.0f} s")
