@@ -114,6 +114,9 @@ struct rsx_engine {
 
     uint32_t* table = nullptr;                  // "histograms": [digit][tile]
     uint32_t* globsum = nullptr;                // block sums of the table scan
+    uint32_t* globsum2 = nullptr;               // their scanned copy when scan #2 ran inside the paste
+    uint32_t* globsum_live = nullptr;           // which of the two a download should read
+    int paste_scan = 1;                         // rsx_sort: scan #2 + paste in one launch (env RSX_PASTE_SCAN)
     uint32_t* temp = nullptr;                   // grand total of scan #2
     uint32_t* counts_next = nullptr;            // look-ahead histogram of the next pass, [tile][digit]
     uint32_t* ref_table = nullptr;              // diagnostics in the reference's [digit][group][item] geometry
@@ -232,11 +235,13 @@ int launch_histogram(rsx_engine* e, const void* in, uint64_t count, int shift, u
     return RSX_OK;
 }
 
-int launch_scan(rsx_engine* e, uint64_t count, bool from_counts = false)
+// scan_level2 = false: only scan #1 runs and globsum keeps the RAW group sums (for launch_paste_scan)
+int launch_scan(rsx_engine* e, uint64_t count, bool from_counts = false, bool scan_level2 = true)
 {
     if (count == 0) return RSX_OK;
     const uint32_t ntiles = static_cast<uint32_t>(e->ntiles(count));
     const uint32_t ngroups = (ntiles + rsx::kScanTiles - 1) / rsx::kScanTiles;
+    e->globsum_live = e->globsum;
     {
         Bracket b(e, PH_SCAN);
         if (from_counts && e->scan_zeroes) {
@@ -251,11 +256,25 @@ int launch_scan(rsx_engine* e, uint64_t count, bool from_counts = false)
         }
     }
     RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
-    {
+    if (scan_level2) {
         Bracket b(e, PH_SCAN);
         hipLaunchKernelGGL(rsx::scan_globsum_kernel, dim3(1), dim3(rsx::kGlobsumThreads), 0, e->stream, e->globsum, e->temp,
                            static_cast<uint32_t>(RSX_RADIX) * ngroups);
     }
+    RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
+    return RSX_OK;
+}
+
+// rsx_sort only: scan #2 and paste in one launch (every workgroup reduces the raw group sums itself)
+int launch_paste_scan(rsx_engine* e, uint64_t count)
+{
+    if (count == 0) return RSX_OK;
+    const uint32_t ntiles = static_cast<uint32_t>(e->ntiles(count));
+    const uint32_t ngroups = (ntiles + rsx::kScanTiles - 1) / rsx::kScanTiles;
+    e->globsum_live = e->globsum2;
+    Bracket b(e, PH_PASTE);
+    hipLaunchKernelGGL(rsx::paste_scan_kernel, dim3(ngroups), dim3(rsx::kScanTiles), 0, e->stream, e->table, e->globsum, e->globsum2, e->temp,
+                       ntiles, ngroups);
     RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
     return RSX_OK;
 }
@@ -409,13 +428,14 @@ int sort_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext_
             rc = first ? launch_histogram<Key>(e, in, count, shift, RSX_RADIX - 1) : RSX_OK;
             bool pasted = false;
             if (rc == RSX_OK) pasted = launch_scan_small(e, count, /*from_counts=*/!first, &rc);
-            if (rc == RSX_OK && !pasted) rc = launch_scan(e, count, /*from_counts=*/!first);
+            const bool merged = e->paste_scan && !e->fold_paste;     // scan #2 inside the paste launch
+            if (rc == RSX_OK && !pasted) rc = launch_scan(e, count, /*from_counts=*/!first, /*scan_level2=*/!merged);
             // small tables were scanned and pasted in one launch; otherwise the paste kernel runs
             // (RSX_FOLD_PASTE=1 lets the reorder add globsum[group] itself instead — measured slower;
             // the last pass always pastes so that a downloaded table is the global prefix in any mode)
             const bool last = pass + 1 == e->last_pass;
             const bool fold = e->fold_paste && !last && !pasted;
-            if (rc == RSX_OK && !fold && !pasted) rc = launch_paste(e, count);
+            if (rc == RSX_OK && !fold && !pasted) rc = merged ? launch_paste_scan(e, count) : launch_paste(e, count);
             const int next_shift = last ? -1 : shift + RSX_RADIX_BITS;
             if (rc == RSX_OK && !last && !e->scan_zeroes) {
                 if (hipMemsetAsync(e->counts_next, 0, static_cast<size_t>(e->ntiles(count)) * RSX_RADIX * 4, e->stream) != hipSuccess) rc = RSX_CALCULATION_FAILED;
@@ -575,6 +595,7 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
     if (const char* env = std::getenv("RSX_LOOKAHEAD")) e->lookahead = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_GRAPH")) e->use_graph = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_SMALL_SCAN")) e->small_scan = std::atoi(env) != 0;
+    if (const char* env = std::getenv("RSX_PASTE_SCAN")) e->paste_scan = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_FOLD_PASTE")) e->fold_paste = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_SCAN_ZEROES")) e->scan_zeroes = std::atoi(env) != 0;
 
@@ -608,6 +629,9 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
         return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(look-ahead counts)", err);
     if ((err = hipMalloc(reinterpret_cast<void**>(&e->globsum), rsx::kMaxScanBlocks * 4)) != hipSuccess)
         return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(globsum)", err);
+    if ((err = hipMalloc(reinterpret_cast<void**>(&e->globsum2), rsx::kMaxScanBlocks * 4)) != hipSuccess)
+        return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(globsum2)", err);
+    e->globsum_live = e->globsum;
     if ((err = hipMalloc(reinterpret_cast<void**>(&e->temp), 64)) != hipSuccess)
         return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(temp)", err);
     if ((err = hipMalloc(reinterpret_cast<void**>(&e->ref_table), rsx::kRefTable * 4)) != hipSuccess)
@@ -667,6 +691,7 @@ int rsx_destroy(rsx_engine* e)
     if (e->table && hipFree(e->table) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->counts_next && hipFree(e->counts_next) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->globsum && hipFree(e->globsum) != hipSuccess) status = RSX_CLEANUP_FAILED;
+    if (e->globsum2 && hipFree(e->globsum2) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->temp && hipFree(e->temp) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->starts_dev && hipFree(e->starts_dev) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->range_dev && hipFree(e->range_dev) != hipSuccess) status = RSX_CLEANUP_FAILED;
@@ -833,7 +858,7 @@ int rsx_download(rsx_engine* e, void* host_keys_out, uint32_t* host_perm_out, ui
     }
     if (globsum_out && globsum_cap) {
         const uint64_t take = std::min<uint64_t>(globsum_cap, rsx::kMaxScanBlocks);
-        RSX_TRY(hipMemcpyAsync(globsum_out, e->globsum, take * 4, hipMemcpyDeviceToHost, e->stream), RSX_DATA_DOWNLOAD_FAILED);
+        RSX_TRY(hipMemcpyAsync(globsum_out, e->globsum_live, take * 4, hipMemcpyDeviceToHost, e->stream), RSX_DATA_DOWNLOAD_FAILED);
     }
     RSX_TRY(hipStreamSynchronize(e->stream), RSX_DATA_DOWNLOAD_FAILED);
     return RSX_OK;

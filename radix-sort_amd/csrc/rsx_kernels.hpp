@@ -343,6 +343,81 @@ __global__ __launch_bounds__(kScanTiles) void paste_kernel(uint32_t* __restrict_
     }
 }
 
+// paste with scan #2 folded in (rsx_sort path): every workgroup derives the 16 global offsets of ITS
+// group straight from the RAW group sums — sum of all groups of smaller digits plus the groups
+// before it in its own digit row — and applies them.  All workgroups redo the (tiny, L2-resident)
+// reduction instead of waiting for a one-workgroup scan kernel: one launch less per pass.  The
+// scanned values are also written to `scanned` so that a downloaded globsum looks the same.
+__global__ __launch_bounds__(kScanTiles) void paste_scan_kernel(uint32_t* __restrict__ table, const uint32_t* __restrict__ raw_sums,
+                                                                 uint32_t* __restrict__ scanned, uint32_t* __restrict__ temp,
+                                                                 uint32_t ntiles, uint32_t ngroups)
+{
+    constexpr int WAVES = kScanTiles / kWave;
+    __shared__ uint32_t part[WAVES][2 * kRadix];
+    __shared__ uint32_t dtot[kRadix];
+    __shared__ uint32_t off[kRadix];
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    const uint32_t group = blockIdx.x;
+    uint32_t pre[kRadix], tot[kRadix];
+#pragma unroll
+    for (int d = 0; d < kRadix; ++d) {
+        pre[d] = 0;
+        tot[d] = 0;
+    }
+    for (uint32_t g2 = tid; g2 < ngroups; g2 += kScanTiles) {
+#pragma unroll
+        for (int d = 0; d < kRadix; ++d) {
+            const uint32_t v = raw_sums[static_cast<uint64_t>(d) * ngroups + g2];
+            tot[d] += v;
+            pre[d] += (g2 < group) ? v : 0u;
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < kRadix; ++d) {
+        const uint32_t a = wave_inclusive_scan(pre[d]);
+        const uint32_t b = wave_inclusive_scan(tot[d]);
+        if (lane == kWave - 1) {
+            part[wave][d] = a;
+            part[wave][kRadix + d] = b;
+        }
+    }
+    __syncthreads();
+    if (tid < kRadix) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            t += part[w][kRadix + tid];
+        }
+        dtot[tid] = t;
+    }
+    __syncthreads();
+    if (tid < kRadix) {
+        uint32_t base = 0;
+#pragma unroll 1
+        for (uint32_t d2 = 0; d2 < tid; ++d2) {
+            base += dtot[d2];
+        }
+        uint32_t p = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            p += part[w][tid];
+        }
+        off[tid] = base + p;
+        scanned[static_cast<uint64_t>(tid) * ngroups + group] = base + p;
+        if (group == 0 && tid == kRadix - 1) {
+            temp[0] = base + dtot[tid];
+        }
+    }
+    __syncthreads();
+    const uint32_t tile = group * kScanTiles + tid;
+    if (tile < ntiles) {
+#pragma unroll
+        for (int d = 0; d < kRadix; ++d) {
+            table[static_cast<uint64_t>(d) * ntiles + tile] += off[d];
+        }
+    }
+}
+
 // Whole table scan in ONE workgroup — scan #1, scan #2 and paste of a small table in a single
 // launch.  Up to 2^22 keys a pass is so short that the three tiny kernels above and their launch
 // boundaries (~15 us together) dominate it; one 1024-thread workgroup walks a table of at most
