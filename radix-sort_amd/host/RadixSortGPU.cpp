@@ -13,12 +13,7 @@ constexpr int key_is_signed = std::is_signed_v<T> ? 1 : 0;
 void accumulate(Statistics& dst, const rsx_phase_stat& src)
 {
     // rsx_timings was read with reset=1: src holds only samples not yet folded in
-    if (src.n == 0) return;
-    dst.n += src.n;
-    dst.sum += src.sum_ms;
-    dst.avg = dst.sum / static_cast<double>(dst.n);
-    if (src.max_ms > dst.max) dst.max = src.max_ms;
-    if (src.min_ms < dst.min) dst.min = src.min_ms;
+    dst.merge(static_cast<std::size_t>(src.n), src.sum_ms, src.min_ms, src.max_ms);
 }
 
 }  // namespace
