@@ -1,69 +1,109 @@
-// basic_sort.cpp — smallest end-user program of the public API, the counterpart of the
-// reference's examples/basic_sort/basic_sort.cpp:23-139: caller-owned vectors -> HostSpans
-// -> initialize -> (padGPUData) -> uploadData -> calculate -> downloadData -> compare with
-// std::sort -> getRuntimes -> release.  Returns non-zero on mismatch.
+// basic_sort.cpp — the smallest complete program on the public API; plays the role of the
+// reference's examples/basic_sort/basic_sort.cpp:23-139 (2^20 random uint32 keys, compare with
+// std::sort, print the per-step timings, non-zero exit code on mismatch).
 //
-//   basic_sort [num_elements]        (default 2^20, like the reference)
+//   basic_sort [num_elements] [--int64] [--argsort] [--pinned]
+//
+// The call sequence is the API contract: caller-owned vectors -> HostSpans -> initialize ->
+// (padGPUData) -> uploadData -> calculate -> downloadData -> getRuntimes -> release.
 #include "Common/ComputeState.h"
 #include "Dataset.h"
+#include "HostData.h"
 #include "Parameters.h"
 #include "RadixSortGPU.h"
 
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
 #include <iostream>
 #include <numeric>
-#include <vector>
+#include <string>
 
-template <typename DataType>
-static bool sortAndVerify(ComputeState& compute, std::uint32_t numElements)
+namespace {
+
+struct Choices {
+    std::uint32_t count = 1U << 20U;
+    bool wide = false;       // int64 keys instead of uint32
+    bool argsort = false;    // carry h_Permut through the sort
+    bool pinned = false;
+};
+
+Choices parse(int argc, char** argv)
 {
-    using Parameters = AlgorithmParameters<DataType>;
-    RandomDistributed<DataType> dataset(numElements);
-
-    RadixSortGPU<DataType> sorter;
-    const std::uint32_t numRounded = sorter.Resize(numElements);
-
-    std::vector<DataType> hKeys(numRounded), hResult(numRounded);
-    std::vector<std::uint32_t> hHistograms(Parameters::_RADIX * Parameters::_NUM_ITEMS), hGlobsum(Parameters::_NUM_HISTOSPLIT), hPermut(numRounded);
-    std::copy_n(dataset.dataset.begin(), numElements, hKeys.begin());
-    std::iota(hPermut.begin(), hPermut.end(), 0U);
-
-    HostSpans<DataType> spans{
-        {hKeys.data(), hKeys.size()}, {hHistograms.data(), hHistograms.size()}, {hGlobsum.data(), hGlobsum.size()},
-        {hPermut.data(), hPermut.size()}, {hResult.data(), hResult.size()},
-    };
-    if (sorter.initialize(compute.device(), compute.m_CLContext, numElements, spans) != OperationStatus::OK) {
-        std::cerr << "Failed to initialize RadixSortGPU\n";
-        return false;
+    Choices c;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        if (a == "--int64") c.wide = true;
+        else if (a == "--argsort") c.argsort = true;
+        else if (a == "--pinned") c.pinned = true;
+        else c.count = static_cast<std::uint32_t>(std::strtoul(a.c_str(), nullptr, 0));
     }
-    auto& queue = compute.m_CLCommandQueue;
-    if (numRounded != numElements) sorter.padGPUData(queue, sizeof(DataType) * numElements);
-    if (sorter.uploadData(queue) != OperationStatus::OK) return std::cerr << "Upload failed\n", false;
-    if (sorter.calculate(queue) != OperationStatus::OK) return std::cerr << "GPU sort failed\n", false;
-    if (sorter.downloadData(queue) != OperationStatus::OK) return std::cerr << "Download failed\n", false;
-
-    // the sort covers the rounded length, whose tail is the host buffer's zeros: compare like with like
-    std::vector<DataType> reference(hKeys);
-    std::sort(reference.begin(), reference.end());
-    const bool correct = std::equal(reference.begin(), reference.end(), hResult.begin());
-
-    const auto rt = sorter.getRuntimes();
-    std::cout << "\n--- Timing (avg ms per launch) ---\n"
-              << "  Histogram : " << rt.timeHisto.avg << "\n  Scan      : " << rt.timeScan.avg << "\n  Reorder   : " << rt.timeReorder.avg
-              << "\n  Paste     : " << rt.timePaste.avg << "\n  Total     : " << rt.timeTotal.avg << "\n";
-    sorter.release();
-    return correct;
+    return c;
 }
+
+template <typename Key>
+bool run(ComputeState& gpu, const Choices& opt)
+{
+    RadixSortGPU<Key> sorter;
+    sorter.enablePermutation(opt.argsort);
+    sorter.enablePinnedTransfers(opt.pinned);
+
+    // the engine sorts Resize(count) elements: whatever the host buffer holds past `count`
+    // (zeros here) is part of the sorted range, exactly as in the reference
+    const std::uint32_t rounded = sorter.Resize(opt.count);
+    HostData<Key> host;
+    host.m_hKeys.assign(rounded, Key{0});
+    host.m_hResultFromGPU.assign(rounded, Key{0});
+    host.m_hHistograms.assign(AlgorithmParameters<Key>::_HISTOSIZE, 0U);
+    host.m_hGlobsum.assign(AlgorithmParameters<Key>::_NUM_HISTOSPLIT, 0U);
+    host.h_Permut.resize(rounded);
+    std::iota(host.h_Permut.begin(), host.h_Permut.end(), 0U);
+    {
+        const RandomDistributed<Key> input(opt.count);
+        std::copy(input.dataset.begin(), input.dataset.end(), host.m_hKeys.begin());
+    }
+
+    const auto fail = [&](const char* step, OperationStatus s) {
+        std::cerr << step << " failed: " << to_string(s) << " (" << rsx_last_error() << ")\n";
+        return false;
+    };
+    auto& queue = gpu.m_CLCommandQueue;
+    OperationStatus s = sorter.initialize(gpu.device(), gpu.m_CLContext, opt.count, MakeHostSpans(host));
+    if (s != OperationStatus::OK) return fail("initialize", s);
+    if (rounded != opt.count) sorter.padGPUData(queue, sizeof(Key) * opt.count);   // overwritten by the upload, as in the reference
+    if ((s = sorter.uploadData(queue)) != OperationStatus::OK) return fail("uploadData", s);
+    if ((s = sorter.calculate(queue)) != OperationStatus::OK) return fail("calculate", s);
+    if ((s = sorter.downloadData(queue)) != OperationStatus::OK) return fail("downloadData", s);
+
+    std::vector<Key> expect(host.m_hKeys);
+    std::sort(expect.begin(), expect.end());
+    bool ok = expect == host.m_hResultFromGPU;
+    if (opt.argsort) {
+        for (std::uint32_t i = 0; i < rounded && ok; ++i) {
+            const std::uint32_t from = host.h_Permut[i];
+            ok = from < rounded && host.m_hKeys[from] == host.m_hResultFromGPU[i] &&
+                 (i == 0 || host.m_hResultFromGPU[i - 1] != host.m_hResultFromGPU[i] || host.h_Permut[i - 1] < from);
+        }
+    }
+
+    const RuntimesGPU t = sorter.getRuntimes();
+    std::cout << "per-launch averages [ms]: histogram " << t.timeHisto.avg << "  scan " << t.timeScan.avg << "  paste " << t.timePaste.avg
+              << "  reorder " << t.timeReorder.avg << "  (sum " << t.timeTotal.avg << ")\n";
+    sorter.release();
+    return ok;
+}
+
+}  // namespace
 
 int main(int argc, char** argv)
 {
-    ComputeState compute;
-    if (!compute.init()) return 1;
-    const std::uint32_t N = argc > 1 ? static_cast<std::uint32_t>(std::strtoul(argv[1], nullptr, 0)) : (1U << 20U);
-    std::cout << "Sorting " << N << " uint32_t values on the GPU...\n";
-    const bool ok = sortAndVerify<std::uint32_t>(compute, N);
-    std::cout << "\nResult: " << (ok ? "PASSED" : "FAILED") << "\n";
+    const Choices opt = parse(argc, argv);
+    ComputeState gpu;
+    if (!gpu.init()) return 1;
+    std::cout << "Sorting " << opt.count << (opt.wide ? " int64_t" : " uint32_t") << " values on the GPU"
+              << (opt.argsort ? " (with permutation)" : "") << "...\n";
+    const bool ok = opt.wide ? run<std::int64_t>(gpu, opt) : run<std::uint32_t>(gpu, opt);
+    std::cout << "Result: " << (ok ? "PASSED" : "FAILED") << "\n";
     return ok ? 0 : 1;
 }
