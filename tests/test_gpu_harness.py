@@ -50,6 +50,8 @@ def test_basic_sort_example():
     assert "Result: PASSED" in proc.stdout
     proc = _run([os.path.join(BIN, "basic_sort"), "1000003"])
     assert proc.returncode == 0 and "Result: PASSED" in proc.stdout
+    proc = _run([os.path.join(BIN, "basic_sort"), "77777", "--int64", "--argsort", "--pinned"])
+    assert proc.returncode == 0 and "Result: PASSED" in proc.stdout, proc.stdout[-1000:] + proc.stderr[-1000:]
 
 
 def test_pinned_transfers_and_sweep_csv(tmp_path):
