@@ -55,11 +55,11 @@ void writePerformance(std::ostream& stream, const RuntimesGPU& g, const Runtimes
 
 template <typename T>
 CRadixSortTask<T>::CRadixSortTask(const RadixSortOptions& options, std::shared_ptr<Dataset<T>> dataset)
-    : mNumberKeys(static_cast<std::uint32_t>(options.num_elements)),
-      mNumberKeysRounded(static_cast<std::uint32_t>(options.num_elements)),
-      mHostData(dataset, options.num_elements),
+    : mOptions(options),
       m_selectedDataset(dataset),
-      mOptions(options)
+      mHostData(dataset, options.num_elements),
+      mNumberKeys(static_cast<std::uint32_t>(options.num_elements)),
+      mNumberKeysRounded(static_cast<std::uint32_t>(options.num_elements))
 {
 }
 
