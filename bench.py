@@ -141,7 +141,7 @@ def main() -> None:
     # timed region: HIP events bracket only the graded reorder launches (8 pairs per sort);
     # the per-phase table below comes from a fully instrumented step after it
     eng.set_option(rsx.OPT_PROFILE, 0 if args.no_events else 2)
-    sorter = ShardedSorter(eng, rank, world, key_bytes * 8, dist, force_exchange=force_exchange)
+    sorter = ShardedSorter(eng, rank, world, key_bytes * 8, dist, force_exchange=force_exchange, strategy=os.environ.get("RSX_STRATEGY", "auto"))
     staging = recv = spay = rpay = None
     if sharded:
         staging = torch.empty_like(keys)
@@ -213,7 +213,7 @@ def main() -> None:
         "dtype": {"uint32": "u32", "int32": "i32", "uint64": "u64", "int64": "i64"}[args.dtype],
         "data": "synthetic",
         "config": {"workload": workload, "keys_per_gpu": n, "total_keys": total_keys,
-                   "parallelism": "single GPU" if not sharded else f"msd-partition x{world} + all_to_all (RCCL) + local LSD sort",
+                   "parallelism": "single GPU" if not sharded else f"msd-partition[{sorter.last_path}] x{world} + all_to_all (RCCL) + local LSD sort",
                    "verified": ok},
         "roofline": {
             "bound": "hbm", "kernel": "reorder_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -189,6 +189,17 @@ int rsx_partition(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, 
 int rsx_partition_count(rsx_engine* e, const void* d_keys, uint64_t n, int shift, int bits, uint64_t* bucket_counts);
 int rsx_partition_scatter(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n, int shift, int bits,
                           void* d_keys_out, uint32_t* d_payload_out);
+/* Splitter partition (multi-GPU exchange on arbitrary distributions, heavy ties included):
+ * rsx_sample_keys: `count` (<= 4096) keys, one per stratum of n/count consecutive keys, in unsigned
+ *   sort order (key ^ sign bit) as uint64.  Synchronises.
+ * rsx_partition_count_split: nsplit (1..7) strictly increasing splitters in that same order;
+ *   bucket(x) = 2 * #{splitters < x} + [x equals a splitter]: even buckets are the open intervals, odd
+ *   buckets hold exactly the keys equal to a splitter (which the caller may cut anywhere, in (rank,
+ *   index) order).  Returns the 2*nsplit+1 bucket sizes.  Synchronises.
+ * rsx_partition_scatter_split: must follow on the same keys; scan + paste + reorder by those buckets. */
+int rsx_sample_keys(rsx_engine* e, const void* d_keys, uint64_t n, uint32_t count, uint64_t* samples);
+int rsx_partition_count_split(rsx_engine* e, const void* d_keys, uint64_t n, const uint64_t* splitters, int nsplit, uint64_t* bucket_counts);
+int rsx_partition_scatter_split(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n, void* d_keys_out, uint32_t* d_payload_out);
 int rsx_key_range(rsx_engine* e, const void* d_keys, uint64_t n, uint64_t* lo, uint64_t* hi);
 int rsx_partition_range(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n, uint64_t lo, int shift, uint64_t mul,
                         void* d_keys_out, uint32_t* d_payload_out, uint64_t* bucket_offsets);

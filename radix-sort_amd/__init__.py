@@ -38,7 +38,7 @@ SYMBOLS = [
     "rsx_create", "rsx_destroy", "rsx_set_stream", "rsx_set_option", "rsx_get_geometry", "rsx_resize",
     "rsx_upload", "rsx_fill_pad", "rsx_download", "rsx_pin_host", "rsx_unpin_host",
     "rsx_histogram", "rsx_scan", "rsx_paste", "rsx_reorder", "rsx_sort", "rsx_sync",
-    "rsx_sort_from", "rsx_partition", "rsx_partition_count", "rsx_partition_scatter", "rsx_key_range", "rsx_partition_range", "rsx_result_device", "rsx_copy_result", "rsx_timings",
+    "rsx_sort_from", "rsx_partition", "rsx_partition_count", "rsx_partition_scatter", "rsx_sample_keys", "rsx_partition_count_split", "rsx_partition_scatter_split", "rsx_key_range", "rsx_partition_range", "rsx_result_device", "rsx_copy_result", "rsx_timings",
 ]
 
 
@@ -128,6 +128,9 @@ def load_library() -> C.CDLL:
         "rsx_partition": ([P, P, P, U64, I, I, P, P, C.POINTER(U64)], I),
         "rsx_partition_count": ([P, P, U64, I, I, C.POINTER(U64)], I),
         "rsx_partition_scatter": ([P, P, P, U64, I, I, P, P], I),
+        "rsx_sample_keys": ([P, P, U64, C.c_uint32, C.POINTER(U64)], I),
+        "rsx_partition_count_split": ([P, P, U64, C.POINTER(U64), I, C.POINTER(U64)], I),
+        "rsx_partition_scatter_split": ([P, P, P, U64, P, P], I),
         "rsx_key_range": ([P, P, U64, C.POINTER(U64), C.POINTER(U64)], I),
         "rsx_partition_range": ([P, P, P, U64, U64, I, U64, P, P, C.POINTER(U64)], I),
         "rsx_result_device": ([P, C.POINTER(P), C.POINTER(P)], I),
@@ -289,6 +292,23 @@ class Engine:
         self._check(self.lib.rsx_partition_scatter(
             self._h, C.c_void_p(d_keys), C.c_void_p(d_payload) if d_payload else None, n, shift, bits,
             C.c_void_p(d_keys_out), C.c_void_p(d_payload_out) if d_payload_out else None), "rsx_partition_scatter")
+
+    def sample_keys(self, d_keys: int, n: int, count: int) -> list[int]:
+        out = (C.c_uint64 * count)()
+        self._check(self.lib.rsx_sample_keys(self._h, C.c_void_p(d_keys), n, count, out), "rsx_sample_keys")
+        return [int(v) for v in out]
+
+    def partition_count_split(self, d_keys: int, n: int, splitters: list[int]) -> list[int]:
+        m = len(splitters)
+        arr = (C.c_uint64 * max(m, 1))(*splitters)
+        counts = (C.c_uint64 * (2 * m + 1))()
+        self._check(self.lib.rsx_partition_count_split(self._h, C.c_void_p(d_keys), n, arr, m, counts), "rsx_partition_count_split")
+        return [int(v) for v in counts]
+
+    def partition_scatter_split(self, d_keys: int, n: int, d_keys_out: int, d_payload: int | None = None, d_payload_out: int | None = None) -> None:
+        self._check(self.lib.rsx_partition_scatter_split(
+            self._h, C.c_void_p(d_keys), C.c_void_p(d_payload) if d_payload else None, n,
+            C.c_void_p(d_keys_out), C.c_void_p(d_payload_out) if d_payload_out else None), "rsx_partition_scatter_split")
 
     def key_range(self, d_keys: int, n: int) -> tuple[int, int]:
         lo, hi = C.c_uint64(), C.c_uint64()

@@ -127,6 +127,8 @@ struct rsx_engine {
     const void* last_in = nullptr;              // input buffer and shift of the most recent reorder
     int last_shift = 0;
     int ref_diag = 0;                           // RSX_OPT_REF_DIAGNOSTICS
+    void* splitters_dev = nullptr;              // up to 7 splitters of the current split partition (key-typed)
+    uint32_t nsplit = 0;
     unsigned long long* range_dev = nullptr;    // per-workgroup {min, max} of rsx_key_range
     unsigned long long* range_host = nullptr;   // pinned mirror
     uint32_t* starts_dev = nullptr;             // 16 bucket starts (rsx_partition)
@@ -223,14 +225,14 @@ Grid grid_for(const rsx_engine* e, uint64_t count)
 }
 
 template <typename Key, bool RANGED = false>
-int launch_histogram(rsx_engine* e, const void* in, uint64_t count, int shift, uint32_t mask, Key lo = Key{0}, Key mul = Key{0})
+int launch_histogram(rsx_engine* e, const void* in, uint64_t count, int shift, uint32_t mask, Key lo = Key{0}, Key mul = Key{0}, uint32_t nsplit = 0)
 {
     if (count == 0) return RSX_OK;
     const Grid g = grid_for(e, count);
     Bracket b(e, PH_HISTO);
     hipLaunchKernelGGL((rsx::histogram_kernel<Key, kTileThreads, kKeysPerThread, RANGED>), dim3(g.blocks), dim3(kTileThreads), 0, e->stream,
                        static_cast<const Key*>(in), e->table, count, g.ntiles, g.tiles_per_xcd, e->xcd_remap, shift,
-                       flip_mask<Key>(e), mask, lo, mul);
+                       flip_mask<Key>(e), mask, lo, mul, static_cast<const Key*>(e->splitters_dev), nsplit);
     RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
     return RSX_OK;
 }
@@ -316,7 +318,7 @@ int launch_paste(rsx_engine* e, uint64_t count)
 // and the kernel adds the scanned block sums itself (no paste launch).
 template <typename Key, bool PAYLOAD, bool LOOKAHEAD, bool RANGED = false>
 int launch_reorder_t(rsx_engine* e, const void* in, void* out, const uint32_t* pin, uint32_t* pout, uint64_t count, int shift,
-                     uint32_t mask, int next_shift, bool fold_paste, Key lo = Key{0}, Key mul = Key{0})
+                     uint32_t mask, int next_shift, bool fold_paste, Key lo = Key{0}, Key mul = Key{0}, uint32_t nsplit = 0)
 {
     using L = rsx::ReorderLayout<Key, kTileThreads, kKeysPerThread>;
     const Grid g = grid_for(e, count);
@@ -326,7 +328,8 @@ int launch_reorder_t(rsx_engine* e, const void* in, void* out, const uint32_t* p
     hipLaunchKernelGGL((rsx::reorder_kernel<Key, kTileThreads, kKeysPerThread, PAYLOAD, LOOKAHEAD, RANGED>), dim3(g.blocks), dim3(kTileThreads),
                        L::BYTES, e->stream, static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->table, count,
                        g.ntiles, g.tiles_per_xcd, e->xcd_remap, shift, flip_mask<Key>(e), mask, e->counts_next, next_shift,
-                       fold_paste ? static_cast<const uint32_t*>(e->globsum) : static_cast<const uint32_t*>(nullptr), lo, mul);
+                       fold_paste ? static_cast<const uint32_t*>(e->globsum) : static_cast<const uint32_t*>(nullptr), lo, mul,
+                       static_cast<const Key*>(e->splitters_dev), nsplit);
     RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
     return RSX_OK;
 }
@@ -638,6 +641,8 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
         return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(ref table)", err);
     if ((err = hipMalloc(reinterpret_cast<void**>(&e->ref_globsum), rsx::kRefSplit * 4)) != hipSuccess)
         return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(ref globsum)", err);
+    if ((err = hipMalloc(&e->splitters_dev, 64)) != hipSuccess)
+        return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(splitters)", err);
     if ((err = hipMalloc(reinterpret_cast<void**>(&e->range_dev), kRangeBlocks * 16)) != hipSuccess)
         return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(range)", err);
     if ((err = hipHostMalloc(reinterpret_cast<void**>(&e->range_host), kRangeBlocks * 16, hipHostMallocDefault)) != hipSuccess)
@@ -695,6 +700,7 @@ int rsx_destroy(rsx_engine* e)
     if (e->temp && hipFree(e->temp) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->starts_dev && hipFree(e->starts_dev) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->range_dev && hipFree(e->range_dev) != hipSuccess) status = RSX_CLEANUP_FAILED;
+    if (e->splitters_dev && hipFree(e->splitters_dev) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->ref_table && hipFree(e->ref_table) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->ref_globsum && hipFree(e->ref_globsum) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->range_host && hipHostFree(e->range_host) != hipSuccess) status = RSX_CLEANUP_FAILED;
@@ -1010,6 +1016,10 @@ int rsx_partition_scatter(rsx_engine* e, const void* d_keys, const uint32_t* d_p
                           void* d_keys_out, uint32_t* d_payload_out)
 {
     if (!e) return fail(RSX_CALCULATION_FAILED, "rsx_partition_scatter: null engine");
+    if (n == 0) {
+        e->counted_keys = nullptr;
+        return RSX_OK;
+    }
     if (d_keys != e->counted_keys || n != e->counted_n || shift != e->counted_shift || bits != e->counted_bits)
         return fail(RSX_CALCULATION_FAILED, "rsx_partition_scatter: must follow rsx_partition_count on the same keys and bit field");
     e->counted_keys = nullptr;       // the table is consumed by this call
@@ -1026,6 +1036,96 @@ int rsx_partition_scatter(rsx_engine* e, const void* d_keys, const uint32_t* d_p
     uint32_t* pout = with_payload ? d_payload_out : nullptr;
     return RSX_BY_KEY(e, launch_reorder<uint32_t>(e, d_keys, d_keys_out, pin, pout, n, shift, mask),
                       launch_reorder<uint64_t>(e, d_keys, d_keys_out, pin, pout, n, shift, mask));
+}
+
+int rsx_sample_keys(rsx_engine* e, const void* d_keys, uint64_t n, uint32_t count, uint64_t* samples)
+{
+    if (!e || !samples) return fail(RSX_CALCULATION_FAILED, "rsx_sample_keys: null argument");
+    if (count == 0 || count > static_cast<uint32_t>(kRangeBlocks) * 2) return fail(RSX_CALCULATION_FAILED, "rsx_sample_keys: count must be in [1, 4096]");
+    if (n == 0 || !d_keys) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_sample_keys: no keys");
+    if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
+    if (e->key_bytes == 4) {
+        hipLaunchKernelGGL(rsx::sample_keys_kernel<uint32_t>, dim3((count + 255) / 256), dim3(256), 0, e->stream, static_cast<const uint32_t*>(d_keys), n,
+                           count, flip_mask<uint32_t>(e), e->range_dev);
+    } else {
+        hipLaunchKernelGGL(rsx::sample_keys_kernel<uint64_t>, dim3((count + 255) / 256), dim3(256), 0, e->stream, static_cast<const uint64_t*>(d_keys), n,
+                           count, flip_mask<uint64_t>(e), e->range_dev);
+    }
+    RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
+    RSX_TRY(hipMemcpyAsync(e->range_host, e->range_dev, static_cast<size_t>(count) * 8, hipMemcpyDeviceToHost, e->stream), RSX_CALCULATION_FAILED);
+    RSX_TRY(hipStreamSynchronize(e->stream), RSX_CALCULATION_FAILED);
+    for (uint32_t i = 0; i < count; ++i) samples[i] = e->range_host[i];
+    return RSX_OK;
+}
+
+int rsx_partition_count_split(rsx_engine* e, const void* d_keys, uint64_t n, const uint64_t* splitters, int nsplit, uint64_t* bucket_counts)
+{
+    if (!e || !bucket_counts || (nsplit > 0 && !splitters)) return fail(RSX_CALCULATION_FAILED, "rsx_partition_count_split: null argument");
+    if (nsplit < 1 || nsplit > 7) return fail(RSX_CALCULATION_FAILED, "rsx_partition_count_split: 1..7 splitters");
+    for (int k = 1; k < nsplit; ++k) {
+        if (splitters[k] <= splitters[k - 1]) return fail(RSX_CALCULATION_FAILED, "rsx_partition_count_split: splitters must be strictly increasing");
+    }
+    if (n > e->capacity) return fail(RSX_RESIZE_FAILED, "rsx_partition_count_split: beyond capacity");
+    const uint32_t buckets = 2u * static_cast<uint32_t>(nsplit) + 1u;
+    for (uint32_t d = 0; d < buckets; ++d) bucket_counts[d] = 0;
+    if (n == 0) return RSX_OK;
+    if (!d_keys || !aligned16(d_keys)) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_partition_count_split: keys must be a 16-byte aligned device pointer");
+    if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
+    // splitters arrive in unsigned sort order (uint64); narrow them to the key type on the device side
+    unsigned char packed[64] = {};
+    for (int k = 0; k < nsplit; ++k) {
+        if (e->key_bytes == 4) {
+            if (splitters[k] > 0xFFFFFFFFull) return fail(RSX_CALCULATION_FAILED, "rsx_partition_count_split: splitter exceeds the key width");
+            const uint32_t v = static_cast<uint32_t>(splitters[k]);
+            std::memcpy(packed + 4 * k, &v, 4);
+        } else {
+            std::memcpy(packed + 8 * k, &splitters[k], 8);
+        }
+    }
+    RSX_TRY(hipMemcpyAsync(e->splitters_dev, packed, 64, hipMemcpyHostToDevice, e->stream), RSX_CALCULATION_FAILED);
+    RSX_TRY(hipStreamSynchronize(e->stream), RSX_CALCULATION_FAILED);      // `packed` is a stack buffer
+    e->nsplit = static_cast<uint32_t>(nsplit);
+    const int rc = RSX_BY_KEY(e, (launch_histogram<uint32_t, true>(e, d_keys, n, 0, RSX_RADIX - 1, 0u, 0u, e->nsplit)),
+                              (launch_histogram<uint64_t, true>(e, d_keys, n, 0, RSX_RADIX - 1, 0ull, 0ull, e->nsplit)));
+    if (rc != RSX_OK) return rc;
+    hipLaunchKernelGGL(rsx::digit_totals_kernel, dim3(RSX_RADIX), dim3(256), 0, e->stream, e->table, static_cast<uint32_t>(e->ntiles(n)), e->range_dev);
+    RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
+    RSX_TRY(hipMemcpyAsync(e->range_host, e->range_dev, RSX_RADIX * 8, hipMemcpyDeviceToHost, e->stream), RSX_CALCULATION_FAILED);
+    RSX_TRY(hipStreamSynchronize(e->stream), RSX_CALCULATION_FAILED);
+    for (uint32_t d = 0; d < buckets; ++d) bucket_counts[d] = e->range_host[d];
+    e->counted_keys = d_keys;
+    e->counted_n = n;
+    e->counted_shift = -1;            // marks a splitter count
+    e->counted_bits = nsplit;
+    return RSX_OK;
+}
+
+int rsx_partition_scatter_split(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n, void* d_keys_out, uint32_t* d_payload_out)
+{
+    if (!e) return fail(RSX_CALCULATION_FAILED, "rsx_partition_scatter_split: null engine");
+    if (n == 0) {
+        e->counted_keys = nullptr;
+        return RSX_OK;
+    }
+    if (d_keys != e->counted_keys || n != e->counted_n || e->counted_shift != -1)
+        return fail(RSX_CALCULATION_FAILED, "rsx_partition_scatter_split: must follow rsx_partition_count_split on the same keys");
+    e->counted_keys = nullptr;
+    if (n == 0) return RSX_OK;
+    if (!d_keys_out || !aligned16(d_keys_out)) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_partition_scatter_split: output must be a 16-byte aligned device pointer");
+    const bool with_payload = e->has_payload && d_payload && d_payload_out;
+    if (e->has_payload && !with_payload) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_partition_scatter_split: payload engine needs payload buffers");
+    if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
+    int rc = launch_scan(e, n);
+    if (rc == RSX_OK) rc = launch_paste(e, n);
+    if (rc != RSX_OK) return rc;
+    const uint32_t* pin = with_payload ? d_payload : nullptr;
+    uint32_t* pout = with_payload ? d_payload_out : nullptr;
+    if (e->key_bytes == 4) {
+        return with_payload ? launch_reorder_t<uint32_t, true, false, true>(e, d_keys, d_keys_out, pin, pout, n, 0, RSX_RADIX - 1, 0, false, 0u, 0u, e->nsplit)
+                            : launch_reorder_t<uint32_t, false, false, true>(e, d_keys, d_keys_out, nullptr, nullptr, n, 0, RSX_RADIX - 1, 0, false, 0u, 0u, e->nsplit);
+    }
+    return with_payload ? launch_reorder_t<uint64_t, true, false, true>(e, d_keys, d_keys_out, pin, pout, n, 0, RSX_RADIX - 1, 0, false, 0ull, 0ull, e->nsplit)
+                        : launch_reorder_t<uint64_t, false, false, true>(e, d_keys, d_keys_out, nullptr, nullptr, n, 0, RSX_RADIX - 1, 0, false, 0ull, 0ull, e->nsplit);
 }
 
 int rsx_key_range(rsx_engine* e, const void* d_keys, uint64_t n, uint64_t* lo, uint64_t* hi)

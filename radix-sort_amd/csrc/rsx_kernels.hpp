@@ -91,6 +91,22 @@ __device__ __forceinline__ uint32_t ranged_bucket(uint64_t x, int shift, uint64_
     return q < mask ? static_cast<uint32_t>(q) : mask;
 }
 
+// Bucket by splitters s_0 < s_1 < ... (at most 7, distinct, unsigned order):
+//   bucket(x) = 2 * #{s_k < x} + [x == some s_k]
+// even buckets are the open intervals between splitters, odd buckets hold exactly the keys EQUAL to
+// a splitter — the host may cut those anywhere (ties split by (rank, index)), which is what keeps the
+// ranks balanced when one key value dominates.  Monotone in x; at most 15 buckets.
+template <typename Key>
+__device__ __forceinline__ uint32_t splitter_bucket(Key x, const Key* __restrict__ splitters, uint32_t nsplit)
+{
+    uint32_t b = 0;
+    for (uint32_t k = 0; k < nsplit; ++k) {
+        const Key s = splitters[k];
+        b += (x > s ? 1u : 0u) + (x >= s ? 1u : 0u);
+    }
+    return b;
+}
+
 // Workgroup -> tile.  Hardware deals consecutive workgroup ids round-robin over the 8
 // XCDs (observed, speed only).  With the remap every XCD walks its own contiguous range
 // of tiles, so the seam between the output runs of tiles t and t+1 (same digit,
@@ -152,10 +168,14 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* w
 template <typename Key, int THREADS, int KPT, bool RANGED = false>
 __global__ __launch_bounds__(THREADS) void histogram_kernel(const Key* __restrict__ keys, uint32_t* __restrict__ table,
                                                              uint64_t n, uint32_t ntiles, uint32_t tiles_per_xcd,
-                                                             int remap, int shift, Key flip, uint32_t mask, Key lo, Key mul)
+                                                             int remap, int shift, Key flip, uint32_t mask, Key lo, Key mul,
+                                                             const Key* __restrict__ splitters, uint32_t nsplit)
 {
     auto dig = [=](Key key) -> uint32_t {
         if constexpr (RANGED) {
+            if (nsplit) {
+                return splitter_bucket(static_cast<Key>(key ^ flip), splitters, nsplit);
+            }
             return ranged_bucket(static_cast<Key>((key ^ flip) - lo), shift, mul, mask);
         } else {
             return digit_of(key, shift, flip, mask);
@@ -621,12 +641,16 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
                                                            const uint32_t* __restrict__ table, uint64_t n, uint32_t ntiles,
                                                            uint32_t tiles_per_xcd, int remap, int shift, Key flip, uint32_t mask,
                                                            uint32_t* __restrict__ next_counts, int next_shift,
-                                                           const uint32_t* __restrict__ globsum, Key lo, Key mul)
+                                                           const uint32_t* __restrict__ globsum, Key lo, Key mul,
+                                                           const Key* __restrict__ splitters, uint32_t nsplit)
 {
     using L = ReorderLayout<Key, THREADS, KPT>;
     static_assert(!(RANGED && LOOKAHEAD), "the ranged bucket function is for the one-pass partition only");
     auto dig = [=](Key key) -> uint32_t {
         if constexpr (RANGED) {
+            if (nsplit) {
+                return splitter_bucket(static_cast<Key>(key ^ flip), splitters, nsplit);
+            }
             return ranged_bucket(static_cast<Key>((key ^ flip) - lo), shift, mul, mask);
         } else {
             return digit_of(key, shift, flip, mask);
@@ -981,6 +1005,23 @@ __global__ __launch_bounds__(1024) void ref_scan_kernel(uint32_t* __restrict__ r
     if ((tid & 1u) == 0) {
         ref_globsum[tid >> 1] = before;
     }
+}
+
+// `count` keys picked one per stratum of n/count consecutive keys, at a hashed position inside the
+// stratum; written in unsigned sort order (key ^ flip) as uint64 (splitter selection, multi-GPU)
+template <typename Key>
+__global__ void sample_keys_kernel(const Key* __restrict__ keys, uint64_t n, uint32_t count, Key flip, unsigned long long* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) {
+        return;
+    }
+    const uint64_t lo = static_cast<uint64_t>(i) * n / count, hi = static_cast<uint64_t>(i + 1) * n / count;
+    const uint64_t width = hi > lo ? hi - lo : 1;
+    uint64_t h = (static_cast<uint64_t>(i) + 1) * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29;
+    const uint64_t pos = lo + h % width;
+    out[i] = static_cast<unsigned long long>(static_cast<Key>(keys[pos < n ? pos : n - 1] ^ flip));
 }
 
 // min / max of the keys in unsigned order (key ^ flip); one {min, max} pair per workgroup,

@@ -9,7 +9,17 @@ across shards, but a most-significant-bits partition is, so the data path is:
   keys by the top 4 key bits (`rsx_partition_count`), the counts are exchanged, and if dealing
   those 16 buckets out leaves no rank with more than 1.25x its share, the keys are grouped by
   those bits (`rsx_partition_scatter`) and exchanged — one read less and two host syncs fewer
-  than the general path, which is otherwise:
+  than the general paths.
+
+  Splitter path (the default general path, up to 8 ranks): every rank samples 1024 of its keys
+  (`rsx_sample_keys`), the samples are gathered, and world-1 quantile SPLITTERS are chosen.  Keys
+  are bucketed as 2 * #{splitters < key} + [key equals a splitter] (`rsx_partition_count_split` /
+  `rsx_partition_scatter_split`): even buckets are the open intervals between splitters and move
+  whole; odd buckets hold only keys EQUAL to a splitter, so they may be cut anywhere — ties are
+  split by (rank, index), which keeps the ranks balanced (and the argsort stable) even when one
+  key value is most of the input (`split_plan`).
+
+  Range path (more than 8 ranks, or strategy="range"):
 
   0. every rank finds the min and max of its keys (`rsx_key_range`, one read) and the ranks
      agree on the global range [lo, hi] (`all_gather` of 4 words).  If lo == hi all keys are
@@ -164,10 +174,101 @@ def plan_exchange(bucket_offsets: list[int], rank: int, world_size: int, dist, d
     return ExchangePlan(send=sends[rank], recv=recv_splits(sends, rank))
 
 
+SAMPLES_PER_RANK = 1024
+MAX_SPLITTERS = 7           # 2*7+1 = 15 buckets fit the 16-bucket kernels
+
+
+def choose_splitters(samples: list[list[int]], shard_sizes: list[int], world_size: int) -> list[int]:
+    """world_size-1 weighted quantiles of the gathered samples (each of rank r's samples stands
+    for shard_sizes[r] / len(samples[r]) keys), deduplicated and increasing.  Values are in
+    unsigned sort order.  May return fewer than world_size-1 (down to none, if no rank has keys)."""
+    weighted = []
+    for vals, n in zip(samples, shard_sizes):
+        if n > 0 and vals:
+            weighted.extend((v, n / len(vals)) for v in vals)
+    if not weighted:
+        return []
+    weighted.sort(key=lambda t: t[0])
+    total = sum(w for _, w in weighted)
+    out, run, k = [], 0.0, 1
+    for v, w in weighted:
+        run += w
+        while k < world_size and run * world_size >= k * total:
+            if not out or out[-1] != v:
+                out.append(v)
+            k += 1
+    return out[:MAX_SPLITTERS]
+
+
+def split_cuts(totals: list[int], world_size: int) -> list[int]:
+    """Global positions (in bucket-major, rank-major, index order) where one rank's share ends
+    and the next begins: world_size+1 monotone values from 0 to the number of keys.  The ideal cut
+    k*total/world is kept when it falls inside an odd ("equal to a splitter") bucket and moved to
+    the nearer end of the bucket when it falls inside an even one, which cannot be cut."""
+    total = sum(totals)
+    starts = [0]
+    for c in totals:
+        starts.append(starts[-1] + c)
+    cuts = [0]
+    for k in range(1, world_size):
+        ideal = k * total // world_size
+        cut = ideal
+        for b, c in enumerate(totals):
+            lo, hi = starts[b], starts[b + 1]
+            if lo < ideal < hi:
+                if b % 2 == 0:
+                    cut = lo if ideal - lo <= hi - ideal else hi
+                break
+        cuts.append(max(cut, cuts[-1]))
+    cuts.append(total)
+    return cuts
+
+
+def split_plan(table: list[list[int]], rank: int, world_size: int) -> tuple[ExchangePlan, float]:
+    """Exchange plan of the splitter path from the [source rank][bucket] count table.  Source r's
+    keys of bucket b occupy global positions start_b + sum(table[r'][b] for r' < r) onwards; each
+    rank sends to destination d the part of its keys inside [cut_d, cut_d+1) — contiguous in its
+    bucket-grouped staging buffer and in destination order."""
+    nb = len(table[0])
+    totals = [sum(row[b] for row in table) for b in range(nb)]
+    cuts = split_cuts(totals, world_size)
+    sends = [[0] * world_size for _ in table]
+    pos = 0
+    for b in range(nb):
+        for r, row in enumerate(table):
+            lo, hi = pos, pos + row[b]
+            for d in range(world_size):
+                a, z = max(lo, cuts[d]), min(hi, cuts[d + 1])
+                if z > a:
+                    sends[r][d] += z - a
+            pos = hi
+    loads = [cuts[d + 1] - cuts[d] for d in range(world_size)]
+    ideal = max(1.0, sum(totals) / world_size)
+    return ExchangePlan(send=sends[rank], recv=recv_splits(sends, rank)), max(loads) / ideal
+
+
+def gather_samples(samples: list[int], n_local: int, world_size: int, dist, device) -> tuple[list[list[int]], list[int]]:
+    """Everybody's samples and shard sizes (one all_gather; 64-bit values as two int64 halves)."""
+    if dist is None:
+        return [samples], [n_local]
+    import torch
+
+    m = 0xFFFFFFFF
+    k = SAMPLES_PER_RANK
+    padded = list(samples) + [0] * (k - len(samples))
+    t = torch.tensor([n_local, len(samples)] + [v >> 32 for v in padded] + [v & m for v in padded], dtype=torch.int64, device=device)
+    gathered = torch.empty(world_size * (2 + 2 * k), dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(gathered, t)
+    rows = gathered.cpu().view(world_size, 2 + 2 * k).tolist()
+    sizes = [r[0] for r in rows]
+    out = [[(r[2 + i] << 32) | r[2 + k + i] for i in range(r[1])] for r in rows]
+    return out, sizes
+
+
 class ShardedSorter:
     """Per-rank driver.  Buffers are torch tensors (device memory + RCCL plumbing)."""
 
-    def __init__(self, engine, rank: int, world_size: int, key_bits: int, dist=None, force_exchange: bool = False):
+    def __init__(self, engine, rank: int, world_size: int, key_bits: int, dist=None, force_exchange: bool = False, strategy: str = "auto"):
         self.engine = engine
         self.rank = rank
         self.world = world_size
@@ -177,6 +278,15 @@ class ShardedSorter:
         # collectives then talk to self); lets a 1-GPU box exercise the real RCCL call path
         self.force_exchange = force_exchange and dist is not None
         self.max_imbalance = 1.25      # top-bit buckets are used when no rank would get more than this x its share
+        # general path when the top bits do not balance: "split" (sampled splitters, <= 8 ranks),
+        # "range" (equal-width buckets over the global key range), "auto" = split where possible
+        if strategy not in ("auto", "split", "range", "top"):
+            raise ValueError(f"unknown strategy {strategy!r}")
+        if strategy == "split" and world_size > MAX_SPLITTERS + 1:
+            raise ValueError(f"the splitter path serves at most {MAX_SPLITTERS + 1} ranks")
+        self.strategy = strategy
+        self.last_path = None          # "local" | "top" | "split" | "range" | "equal" (for tests and logs)
+        self.last_imbalance = None
         if world_size > 1 and dist is None:
             raise ValueError("a torch.distributed module is required for world_size > 1")
 
@@ -188,30 +298,54 @@ class ShardedSorter:
         n = keys.numel()
         if self.world == 1 and not self.force_exchange:
             self.engine.sort_from(keys.data_ptr(), n, payload.data_ptr() if payload is not None else None)
+            self.last_path = "local"
             return n
-        # fast path: buckets on the top 4 key bits, if they deal out evenly
-        top_shift = self.key_bits - PARTITION_BITS
-        table = gather_counts(self.engine.partition_count(keys.data_ptr(), n, top_shift, PARTITION_BITS), self.world, self.dist, keys.device)
-        plan, imbalance = plan_from_table(table, self.rank, self.world)
-        if imbalance <= self.max_imbalance:
-            self.engine.partition_scatter(
-                keys.data_ptr(), n, top_shift, PARTITION_BITS, staging.data_ptr(),
-                payload.data_ptr() if payload is not None else None,
-                staging_payload.data_ptr() if staging_payload is not None else None)
-            return self._exchange_and_sort(plan, n, staging, recv, payload, staging_payload, recv_payload)
+        pay_in = payload.data_ptr() if payload is not None else None
+        pay_st = staging_payload.data_ptr() if staging_payload is not None else None
+        if self.strategy in ("auto", "top"):
+            # fast path: buckets on the top 4 key bits, if they deal out evenly
+            top_shift = self.key_bits - PARTITION_BITS
+            table = gather_counts(self.engine.partition_count(keys.data_ptr(), n, top_shift, PARTITION_BITS), self.world, self.dist, keys.device)
+            plan, imbalance = plan_from_table(table, self.rank, self.world)
+            if imbalance <= self.max_imbalance or self.strategy == "top":
+                self.engine.partition_scatter(keys.data_ptr(), n, top_shift, PARTITION_BITS, staging.data_ptr(), pay_in, pay_st)
+                self.last_path, self.last_imbalance = "top", imbalance
+                return self._exchange_and_sort(plan, n, staging, recv, payload, staging_payload, recv_payload)
+        if self.strategy == "split" or (self.strategy == "auto" and self.world <= MAX_SPLITTERS + 1):
+            return self._sort_by_splitters(keys, n, staging, recv, payload, staging_payload, recv_payload, pay_in, pay_st)
         lo, hi = self.engine.key_range(keys.data_ptr(), n)
         lo, hi = global_key_range(lo, hi, self.world, self.dist, keys.device)
         if lo >= hi:
             # every key everywhere is the same value (or there are no keys): rank-order
             # concatenation is already sorted and stable, nothing has to move
             self.engine.sort_from(keys.data_ptr(), n, payload.data_ptr() if payload is not None else None)
+            self.last_path = "equal"
             return n
+        self.last_path = "range"
         shift, mul = range_buckets(lo, hi, self.key_bits)
         offs = self.engine.partition_range(
             keys.data_ptr(), n, lo, shift, mul, staging.data_ptr(),
             payload.data_ptr() if payload is not None else None,
             staging_payload.data_ptr() if staging_payload is not None else None)
         plan = plan_exchange(offs, self.rank, self.world, self.dist, keys.device)
+        return self._exchange_and_sort(plan, n, staging, recv, payload, staging_payload, recv_payload)
+
+    def _sort_by_splitters(self, keys, n, staging, recv, payload, staging_payload, recv_payload, pay_in, pay_st):
+        count = min(SAMPLES_PER_RANK, n)
+        mine = self.engine.sample_keys(keys.data_ptr(), n, count) if count else []
+        samples, sizes = gather_samples(mine, n, self.world, self.dist, keys.device)
+        splitters = choose_splitters(samples, sizes, self.world)
+        if not splitters:              # nobody has keys
+            self.engine.sort_from(keys.data_ptr(), n, pay_in)
+            self.last_path = "equal"
+            return n
+        counts = self.engine.partition_count_split(keys.data_ptr(), n, splitters)
+        counts = counts + [0] * (RADIX - len(counts))
+        table = gather_counts(counts, self.world, self.dist, keys.device)
+        table = [row[:2 * len(splitters) + 1] for row in table]
+        plan, imbalance = split_plan(table, self.rank, self.world)
+        self.engine.partition_scatter_split(keys.data_ptr(), n, staging.data_ptr(), pay_in, pay_st)
+        self.last_path, self.last_imbalance = "split", imbalance
         return self._exchange_and_sort(plan, n, staging, recv, payload, staging_payload, recv_payload)
 
     def _exchange_and_sort(self, plan, n, staging, recv, payload, staging_payload, recv_payload):

@@ -115,6 +115,29 @@ class _CpuEngineDouble:
             self._view(d_payload_out, n, np.uint32)[:] = self._view(d_payload, n, np.uint32)[order]
         return [0] + [int(v) for v in np.cumsum(np.bincount(d, minlength=16))]
 
+    def sample_keys(self, d_keys, n, count):
+        u = self._biased(self._view(d_keys, n, self.dtype))
+        return [int(u[(2 * i + 1) * n // (2 * count)]) for i in range(count)]
+
+    @staticmethod
+    def _split_buckets(u, splitters):
+        sp = np.array(splitters, dtype=u.dtype)
+        return (np.searchsorted(sp, u, side="left") + np.searchsorted(sp, u, side="right")).astype(np.int64)
+
+    def partition_count_split(self, d_keys, n, splitters):
+        assert 1 <= len(splitters) <= 7 and splitters == sorted(set(splitters))
+        self._split = (d_keys, n, list(splitters))
+        d = self._split_buckets(self._biased(self._view(d_keys, n, self.dtype)), splitters)
+        return [int(v) for v in np.bincount(d, minlength=2 * len(splitters) + 1)]
+
+    def partition_scatter_split(self, d_keys, n, d_keys_out, d_payload=None, d_payload_out=None):
+        assert self._split[:2] == (d_keys, n)
+        keys = self._view(d_keys, n, self.dtype)
+        order = np.argsort(self._split_buckets(self._biased(keys), self._split[2]), kind="stable")
+        self._view(d_keys_out, n, self.dtype)[:] = keys[order]
+        if d_payload:
+            self._view(d_payload_out, n, np.uint32)[:] = self._view(d_payload, n, np.uint32)[order]
+
     def sort_from(self, d_keys, n, d_payload=None):
         keys = self._view(d_keys, n, self.dtype).copy()
         order = np.argsort(keys, kind="stable")
@@ -131,7 +154,24 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, dtype, kind, with_payload, n_per_rank, q):
+def _make_full(kind, dtype, n, orc):
+    """Reference dataset kinds plus the distributions that stress the exchange plan."""
+    if kind == "HeavyTies":            # 80 % one value in the middle of the key range, rest uniform
+        x = orc.dataset("SeededUniform", dtype, n, seed=77)
+        rng = np.random.default_rng(5)
+        x[rng.random(n) < 0.8] = x.dtype.type(12345)
+        return x
+    if kind == "FewValues":            # three distinct keys
+        rng = np.random.default_rng(6)
+        return np.array([3, 70000, 9], dtype=dtype)[rng.integers(0, 3, n)]
+    if kind == "Skewed":               # exponential magnitudes: equal-width buckets put ~all keys in bucket 0
+        rng = np.random.default_rng(8)
+        bits = np.dtype(dtype).itemsize * 8 - 1
+        return (2.0 ** (rng.random(n) * bits)).astype(np.uint64).astype(dtype)
+    return orc.dataset(kind, dtype, n, seed=77)
+
+
+def _worker(rank, world, port, dtype, kind, with_payload, n_per_rank, q, strategy="auto"):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -141,7 +181,7 @@ def _worker(rank, world, port, dtype, kind, with_payload, n_per_rank, q):
         d = _dist_module()
         from _oracle import Oracle
         orc = Oracle()
-        full = orc.dataset(kind, dtype, n_per_rank * world, seed=77)
+        full = _make_full(kind, dtype, n_per_rank * world, orc)
         shard = full[rank * n_per_rank:(rank + 1) * n_per_rank].copy()
         signed = {"uint32": np.int32, "uint64": np.int64}.get(np.dtype(dtype).name)
         t_keys = torch.from_numpy(shard.view(signed) if signed else shard)
@@ -153,30 +193,37 @@ def _worker(rank, world, port, dtype, kind, with_payload, n_per_rank, q):
             spay = torch.empty_like(pay)
             rpay = torch.empty(n_per_rank * world, dtype=torch.int32)
         eng = _CpuEngineDouble(dtype)
-        sorter = d.ShardedSorter(eng, rank, world, np.dtype(dtype).itemsize * 8, dist)
+        sorter = d.ShardedSorter(eng, rank, world, np.dtype(dtype).itemsize * 8, dist, strategy=strategy)
         n_local = sorter.sort(t_keys, staging, recv, pay, spay, rpay)
-        q.put((rank, n_local, eng.result, eng.result_payload))
+        q.put((rank, n_local, eng.result, eng.result_payload, sorter.last_path))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dtype,kind,with_payload", [
-    ("uint32", "SeededUniform", False),
-    ("int32", "SeededUniform", True),
-    ("uint64", "SeededUniform", True),
-    ("int64", "Random", False),       # all keys are small non-negative: lands on few ranks
-    ("uint32", "Zeros", True),        # every key equal: nothing moves
-    ("int32", "Range", True),         # small range at the bottom of the key space: ranged buckets balance it
-    ("uint64", "InvertedRange", False),
+@pytest.mark.parametrize("dtype,kind,with_payload,strategy", [
+    ("uint32", "SeededUniform", False, "auto"),
+    ("int32", "SeededUniform", True, "auto"),
+    ("uint64", "SeededUniform", True, "split"),
+    ("int64", "Random", False, "auto"),       # all keys are small non-negative: top bits put them on one rank
+    ("uint32", "Zeros", True, "auto"),        # every key equal: the tie bucket is cut at the shard boundary
+    ("uint32", "Zeros", False, "range"),      # ... and the range path's all-equal shortcut
+    ("int32", "Range", True, "auto"),         # small range at the bottom of the key space
+    ("int32", "Range", True, "range"),
+    ("uint64", "InvertedRange", False, "auto"),
+    ("uint64", "InvertedRange", False, "range"),
+    ("uint32", "HeavyTies", True, "auto"),    # 80 % one value: only cutting the tie bucket balances this
+    ("int64", "FewValues", True, "auto"),
+    ("uint32", "Skewed", False, "auto"),
+    ("int64", "Skewed", True, "auto"),
 ])
-def test_sharded_sort_world2(dtype, kind, with_payload):
+def test_sharded_sort_world2(dtype, kind, with_payload, strategy):
     import torch.multiprocessing as mp
     from _oracle import Oracle
     world, n_per_rank = 2, 3000
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, dtype, kind, with_payload, n_per_rank, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, dtype, kind, with_payload, n_per_rank, q, strategy)) for r in range(world)]
     for p in procs:
         p.start()
     outs = sorted((q.get(timeout=180) for _ in range(world)), key=lambda t: t[0])
@@ -184,12 +231,54 @@ def test_sharded_sort_world2(dtype, kind, with_payload):
         p.join(timeout=60)
         assert p.exitcode == 0
     orc = Oracle()
-    full = orc.dataset(kind, dtype, n_per_rank * world, seed=77)
+    full = _make_full(kind, dtype, n_per_rank * world, orc)
     got = np.concatenate([o[2] for o in outs])
     assert sum(o[1] for o in outs) == full.size
     assert np.array_equal(got, np.sort(full, kind="stable"))
-    if kind in ("Range", "InvertedRange", "SeededUniform"):
-        assert max(o[1] for o in outs) <= 0.6 * full.size        # ranged buckets keep the ranks balanced
+    assert len({o[4] for o in outs}) == 1                          # all ranks took the same path
+    if strategy == "auto" and kind != "SeededUniform":
+        assert outs[0][4] == "split"
+    if kind in ("Range", "InvertedRange", "SeededUniform") or strategy != "range":
+        assert max(o[1] for o in outs) <= 0.6 * full.size        # the ranks stay balanced
     if with_payload:
         got_p = np.concatenate([o[3] for o in outs])
         assert np.array_equal(got_p, np.argsort(full, kind="stable").astype(np.uint32))   # global stable argsort
+
+
+def test_choose_splitters_and_split_plan():
+    d = _dist_module()
+    # quantiles of two equally weighted sample sets
+    sp = d.choose_splitters([[1, 2, 3, 4], [5, 6, 7, 8]], [100, 100], 4)
+    assert sp == [2, 4, 6]
+    # weights: rank 1 holds 9x the keys, so the median sits inside its samples
+    assert d.choose_splitters([[1, 2, 3, 4], [5, 6, 7, 8]], [10, 90], 2) == [6]
+    # a dominant value collapses the quantiles into one splitter; empty ranks are skipped
+    assert d.choose_splitters([[7] * 8, []], [50, 0], 8) == [7]
+    assert d.choose_splitters([[], []], [0, 0], 2) == []
+    assert len(d.choose_splitters([list(range(1000))], [1000], 8)) == 7
+
+    # cuts: inside an odd bucket exact, inside an even bucket snapped to the nearer end
+    assert d.split_cuts([0, 100, 0], 4) == [0, 25, 50, 75, 100]
+    assert d.split_cuts([40, 0, 60], 2) == [0, 40, 100]
+    assert d.split_cuts([10, 80, 10], 2) == [0, 50, 100]
+    assert d.split_cuts([0, 0, 0], 3) == [0, 0, 0, 0]
+
+    # all keys equal to the splitter, two ranks with 60 / 40 keys: rank 0 keeps 50, sends 10
+    plan0, imb = d.split_plan([[0, 60, 0], [0, 40, 0]], 0, 2)
+    plan1, _ = d.split_plan([[0, 60, 0], [0, 40, 0]], 1, 2)
+    assert plan0.send == [50, 10] and plan0.recv == [50, 0]
+    assert plan1.send == [0, 40] and plan1.recv == [10, 40] and imb == 1.0
+
+    # every plan conserves keys and is consistent between senders and receivers
+    import random
+    rnd = random.Random(3)
+    for _ in range(200):
+        world = rnd.randint(1, 8)
+        m = rnd.randint(1, 7)
+        table = [[rnd.choice([0, 0, rnd.randint(0, 50), rnd.randint(0, 5000)]) for _ in range(2 * m + 1)] for _ in range(world)]
+        plans = [d.split_plan(table, r, world)[0] for r in range(world)]
+        for r in range(world):
+            assert sum(plans[r].send) == sum(table[r])
+            assert plans[r].recv == [plans[s].send[r] for s in range(world)]
+        cuts = d.split_cuts([sum(row[b] for row in table) for b in range(2 * m + 1)], world)
+        assert cuts == sorted(cuts) and [p.n_recv for p in plans] == [cuts[i + 1] - cuts[i] for i in range(world)]

@@ -50,13 +50,28 @@ class _RankDist:
         self.hub.barrier.wait()
 
 
-@pytest.mark.parametrize("dtype,kind,with_payload", [("uint32", "SeededUniform", False), ("int64", "SeededUniform", True), ("uint32", "Zeros", True),
-                                                      ("int32", "Range", True), ("uint64", "InvertedRange", False)])
-def test_two_ranks_on_one_gpu(rsx, oracle, dtype, kind, with_payload):
+def _make_full(kind, dtype, n, oracle):
+    if kind == "HeavyTies":            # 80 % one value, the rest uniform: only cutting the tie bucket balances it
+        x = oracle.dataset("SeededUniform", dtype, n, seed=31)
+        x[np.random.default_rng(5).random(n) < 0.8] = x.dtype.type(12345)
+        return x
+    if kind == "Skewed":               # exponential magnitudes
+        bits = np.dtype(dtype).itemsize * 8 - 1
+        return (2.0 ** (np.random.default_rng(8).random(n) * bits)).astype(np.uint64).astype(dtype)
+    return oracle.dataset(kind, dtype, n, seed=31)
+
+
+@pytest.mark.parametrize("dtype,kind,with_payload,world,strategy", [
+    ("uint32", "SeededUniform", False, 2, "auto"), ("int64", "SeededUniform", True, 2, "auto"), ("uint32", "Zeros", True, 2, "auto"),
+    ("int32", "Range", True, 2, "auto"), ("uint64", "InvertedRange", False, 2, "auto"),
+    ("int32", "Range", True, 2, "range"), ("uint64", "InvertedRange", False, 2, "range"), ("uint32", "Zeros", True, 2, "range"),
+    ("uint32", "HeavyTies", True, 4, "auto"), ("int64", "HeavyTies", True, 3, "auto"), ("uint64", "Skewed", True, 4, "auto"),
+    ("int32", "Skewed", False, 4, "auto"), ("uint32", "SeededUniform", True, 4, "split"), ("uint32", "Random", False, 4, "auto")])
+def test_ranks_on_one_gpu(rsx, oracle, dtype, kind, with_payload, world, strategy):
     import torch
     from radix_sort_amd.distributed import ShardedSorter
-    world, n = 2, 100003
-    full = oracle.dataset(kind, dtype, n * world, seed=31)
+    n = 100003
+    full = _make_full(kind, dtype, n * world, oracle)
     hub = _Loopback(world)
     results, errors = [None] * world, []
 
@@ -76,10 +91,10 @@ def test_two_ranks_on_one_gpu(rsx, oracle, dtype, kind, with_payload):
                     rpay = torch.empty(n * world, dtype=torch.int32, device="cuda")
                 with rsx.Engine(dtype, n * world, payload=with_payload) as eng:
                     eng.set_stream(stream.cuda_stream)
-                    sorter = ShardedSorter(eng, rank, world, np.dtype(dtype).itemsize * 8, hub.view(rank))
+                    sorter = ShardedSorter(eng, rank, world, np.dtype(dtype).itemsize * 8, hub.view(rank), strategy=strategy)
                     n_local = sorter.sort(keys, staging, recv, pay, spay, rpay)
                     out = eng.download(want_perm=True) if with_payload else (eng.download(), None)
-                    results[rank] = (n_local, out[0], out[1])
+                    results[rank] = (n_local, out[0], out[1], sorter.last_path)
         except Exception as exc:   # noqa: BLE001 - surface in the main thread
             errors.append(exc)
             hub.barrier.abort()
@@ -95,6 +110,55 @@ def test_two_ranks_on_one_gpu(rsx, oracle, dtype, kind, with_payload):
     assert np.array_equal(got, np.sort(full, kind="stable"))
     if with_payload:
         assert np.array_equal(np.concatenate([r[2] for r in results]), np.argsort(full, kind="stable").astype(np.uint32))
+    assert len({r[3] for r in results}) == 1
+    if strategy == "auto":
+        assert results[0][3] == ("top" if kind in ("SeededUniform", "Random") else "split")
+    if strategy != "range":
+        assert max(r[0] for r in results) <= 1.2 * n             # balanced whatever the distribution
+
+
+@pytest.mark.parametrize("dt", ["uint32", "int32", "uint64", "int64"])
+def test_sample_and_split_partition(rsx, oracle, dt):
+    """rsx_sample_keys / rsx_partition_count_split / rsx_partition_scatter_split against numpy."""
+    import torch
+    n = 250007
+    keys = oracle.dataset("SeededUniform", dt, n, seed=9)
+    keys[::3] = keys[5]                                  # a heavy tie that will become a splitter
+    signed = {"uint32": np.int32, "uint64": np.int64}.get(np.dtype(dt).name)
+    tk = torch.from_numpy(keys.view(signed) if signed else keys).cuda()
+    pay = torch.arange(n, dtype=torch.int32, device="cuda")
+    out, pout = torch.empty_like(tk), torch.empty_like(pay)
+    u = keys.view(np.uint32 if keys.dtype.itemsize == 4 else np.uint64)
+    if keys.dtype.kind == "i":
+        u = u ^ u.dtype.type(1 << (keys.dtype.itemsize * 8 - 1))
+    with rsx.Engine(dt, n, payload=True) as e:
+        e.set_stream(torch.cuda.current_stream().cuda_stream)
+        samples = e.sample_keys(tk.data_ptr(), n, 1024)
+        assert len(samples) == 1024 and set(samples) <= set(int(v) for v in u)
+        for i in (0, 1, 500, 1023):                          # one per stratum of n/1024 consecutive keys
+            assert samples[i] in set(int(v) for v in u[i * n // 1024:(i + 1) * n // 1024])
+        ordered = sorted(samples)
+        for m in (1, 3, 7):
+            sp = sorted({ordered[(k + 1) * 1024 // (m + 1)] for k in range(m)} | {int(u[5])})[:7]   # the tie value is a splitter
+            if int(u[5]) not in sp:
+                sp[-1] = int(u[5])
+                sp = sorted(set(sp))
+            spa = np.array(sp, dtype=u.dtype)
+            d = (np.searchsorted(spa, u, side="left") + np.searchsorted(spa, u, side="right")).astype(np.int64)
+            counts = e.partition_count_split(tk.data_ptr(), n, sp)
+            assert counts == [int(v) for v in np.bincount(d, minlength=2 * len(sp) + 1)]
+            assert counts[2 * sp.index(int(u[5])) + 1] >= n // 3
+            e.partition_scatter_split(tk.data_ptr(), n, out.data_ptr(), pay.data_ptr(), pout.data_ptr())
+            torch.cuda.synchronize()
+            order = np.argsort(d, kind="stable")
+            assert np.array_equal(out.cpu().numpy().view(keys.dtype), keys[order])
+            assert np.array_equal(pout.cpu().numpy().view(np.uint32), order.astype(np.uint32))
+        with pytest.raises(rsx.RadixSortError):
+            e.partition_count_split(tk.data_ptr(), n, [5, 5])           # not strictly increasing
+        with pytest.raises(rsx.RadixSortError):
+            e.partition_count_split(tk.data_ptr(), n, list(range(8)))   # too many
+        with pytest.raises(rsx.RadixSortError):
+            e.partition_scatter_split(tk.data_ptr(), n, out.data_ptr(), pay.data_ptr(), pout.data_ptr())   # no count before it
 
 
 def test_world_size_one_is_plain_sort(rsx, oracle):
