@@ -127,7 +127,7 @@ struct rsx_engine {
     const void* last_in = nullptr;              // input buffer and shift of the most recent reorder
     int last_shift = 0;
     int ref_diag = 0;                           // RSX_OPT_REF_DIAGNOSTICS
-    void* splitters_dev = nullptr;              // up to 7 splitters of the current split partition (key-typed)
+    uint64_t splitters[rsx::kMaxSplitters] = {};   // splitters of the current split partition, unsigned sort order
     uint32_t nsplit = 0;
     unsigned long long* range_dev = nullptr;    // per-workgroup {min, max} of rsx_key_range
     unsigned long long* range_host = nullptr;   // pinned mirror
@@ -224,6 +224,16 @@ Grid grid_for(const rsx_engine* e, uint64_t count)
     return g;
 }
 
+// the first `nsplit` splitters of the engine narrowed to the key type (0 = not a splitter launch)
+template <typename Key>
+rsx::SplitSet<Key> split_set(const rsx_engine* e, uint32_t nsplit)
+{
+    rsx::SplitSet<Key> set{};
+    for (uint32_t k = 0; k < nsplit && k < static_cast<uint32_t>(rsx::kMaxSplitters); ++k) set.s[k] = static_cast<Key>(e->splitters[k]);
+    set.n = nsplit;
+    return set;
+}
+
 template <typename Key, bool RANGED = false>
 int launch_histogram(rsx_engine* e, const void* in, uint64_t count, int shift, uint32_t mask, Key lo = Key{0}, Key mul = Key{0}, uint32_t nsplit = 0)
 {
@@ -232,7 +242,7 @@ int launch_histogram(rsx_engine* e, const void* in, uint64_t count, int shift, u
     Bracket b(e, PH_HISTO);
     hipLaunchKernelGGL((rsx::histogram_kernel<Key, kTileThreads, kKeysPerThread, RANGED>), dim3(g.blocks), dim3(kTileThreads), 0, e->stream,
                        static_cast<const Key*>(in), e->table, count, g.ntiles, g.tiles_per_xcd, e->xcd_remap, shift,
-                       flip_mask<Key>(e), mask, lo, mul, static_cast<const Key*>(e->splitters_dev), nsplit);
+                       flip_mask<Key>(e), mask, lo, mul, split_set<Key>(e, nsplit));
     RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
     return RSX_OK;
 }
@@ -328,8 +338,7 @@ int launch_reorder_t(rsx_engine* e, const void* in, void* out, const uint32_t* p
     hipLaunchKernelGGL((rsx::reorder_kernel<Key, kTileThreads, kKeysPerThread, PAYLOAD, LOOKAHEAD, RANGED>), dim3(g.blocks), dim3(kTileThreads),
                        L::BYTES, e->stream, static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->table, count,
                        g.ntiles, g.tiles_per_xcd, e->xcd_remap, shift, flip_mask<Key>(e), mask, e->counts_next, next_shift,
-                       fold_paste ? static_cast<const uint32_t*>(e->globsum) : static_cast<const uint32_t*>(nullptr), lo, mul,
-                       static_cast<const Key*>(e->splitters_dev), nsplit);
+                       fold_paste ? static_cast<const uint32_t*>(e->globsum) : static_cast<const uint32_t*>(nullptr), lo, mul, split_set<Key>(e, nsplit));
     RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
     return RSX_OK;
 }
@@ -641,8 +650,6 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
         return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(ref table)", err);
     if ((err = hipMalloc(reinterpret_cast<void**>(&e->ref_globsum), rsx::kRefSplit * 4)) != hipSuccess)
         return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(ref globsum)", err);
-    if ((err = hipMalloc(&e->splitters_dev, 64)) != hipSuccess)
-        return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(splitters)", err);
     if ((err = hipMalloc(reinterpret_cast<void**>(&e->range_dev), kRangeBlocks * 16)) != hipSuccess)
         return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(range)", err);
     if ((err = hipHostMalloc(reinterpret_cast<void**>(&e->range_host), kRangeBlocks * 16, hipHostMallocDefault)) != hipSuccess)
@@ -700,7 +707,6 @@ int rsx_destroy(rsx_engine* e)
     if (e->temp && hipFree(e->temp) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->starts_dev && hipFree(e->starts_dev) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->range_dev && hipFree(e->range_dev) != hipSuccess) status = RSX_CLEANUP_FAILED;
-    if (e->splitters_dev && hipFree(e->splitters_dev) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->ref_table && hipFree(e->ref_table) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->ref_globsum && hipFree(e->ref_globsum) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->range_host && hipHostFree(e->range_host) != hipSuccess) status = RSX_CLEANUP_FAILED;
@@ -1071,19 +1077,10 @@ int rsx_partition_count_split(rsx_engine* e, const void* d_keys, uint64_t n, con
     if (n == 0) return RSX_OK;
     if (!d_keys || !aligned16(d_keys)) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_partition_count_split: keys must be a 16-byte aligned device pointer");
     if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
-    // splitters arrive in unsigned sort order (uint64); narrow them to the key type on the device side
-    unsigned char packed[64] = {};
     for (int k = 0; k < nsplit; ++k) {
-        if (e->key_bytes == 4) {
-            if (splitters[k] > 0xFFFFFFFFull) return fail(RSX_CALCULATION_FAILED, "rsx_partition_count_split: splitter exceeds the key width");
-            const uint32_t v = static_cast<uint32_t>(splitters[k]);
-            std::memcpy(packed + 4 * k, &v, 4);
-        } else {
-            std::memcpy(packed + 8 * k, &splitters[k], 8);
-        }
+        if (e->key_bytes == 4 && splitters[k] > 0xFFFFFFFFull) return fail(RSX_CALCULATION_FAILED, "rsx_partition_count_split: splitter exceeds the key width");
+        e->splitters[k] = splitters[k];
     }
-    RSX_TRY(hipMemcpyAsync(e->splitters_dev, packed, 64, hipMemcpyHostToDevice, e->stream), RSX_CALCULATION_FAILED);
-    RSX_TRY(hipStreamSynchronize(e->stream), RSX_CALCULATION_FAILED);      // `packed` is a stack buffer
     e->nsplit = static_cast<uint32_t>(nsplit);
     const int rc = RSX_BY_KEY(e, (launch_histogram<uint32_t, true>(e, d_keys, n, 0, RSX_RADIX - 1, 0u, 0u, e->nsplit)),
                               (launch_histogram<uint64_t, true>(e, d_keys, n, 0, RSX_RADIX - 1, 0ull, 0ull, e->nsplit)));

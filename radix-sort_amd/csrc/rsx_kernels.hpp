@@ -96,13 +96,23 @@ __device__ __forceinline__ uint32_t ranged_bucket(uint64_t x, int shift, uint64_
 // even buckets are the open intervals between splitters, odd buckets hold exactly the keys EQUAL to
 // a splitter — the host may cut those anywhere (ties split by (rank, index)), which is what keeps the
 // ranks balanced when one key value dominates.  Monotone in x; at most 15 buckets.
+// The set travels by value in the kernel arguments, so the splitters sit in scalar registers.
+constexpr int kMaxSplitters = 7;
 template <typename Key>
-__device__ __forceinline__ uint32_t splitter_bucket(Key x, const Key* __restrict__ splitters, uint32_t nsplit)
+struct SplitSet {
+    Key s[kMaxSplitters];
+    uint32_t n;
+};
+
+template <typename Key>
+__device__ __forceinline__ uint32_t splitter_bucket(Key x, const SplitSet<Key>& set)
 {
     uint32_t b = 0;
-    for (uint32_t k = 0; k < nsplit; ++k) {
-        const Key s = splitters[k];
-        b += (x > s ? 1u : 0u) + (x >= s ? 1u : 0u);
+#pragma unroll
+    for (int k = 0; k < kMaxSplitters; ++k) {
+        if (k < static_cast<int>(set.n)) {            // wave-uniform
+            b += (x > set.s[k] ? 1u : 0u) + (x >= set.s[k] ? 1u : 0u);
+        }
     }
     return b;
 }
@@ -169,12 +179,12 @@ template <typename Key, int THREADS, int KPT, bool RANGED = false>
 __global__ __launch_bounds__(THREADS) void histogram_kernel(const Key* __restrict__ keys, uint32_t* __restrict__ table,
                                                              uint64_t n, uint32_t ntiles, uint32_t tiles_per_xcd,
                                                              int remap, int shift, Key flip, uint32_t mask, Key lo, Key mul,
-                                                             const Key* __restrict__ splitters, uint32_t nsplit)
+                                                             SplitSet<Key> split)
 {
     auto dig = [=](Key key) -> uint32_t {
         if constexpr (RANGED) {
-            if (nsplit) {
-                return splitter_bucket(static_cast<Key>(key ^ flip), splitters, nsplit);
+            if (split.n) {
+                return splitter_bucket(static_cast<Key>(key ^ flip), split);
             }
             return ranged_bucket(static_cast<Key>((key ^ flip) - lo), shift, mul, mask);
         } else {
@@ -642,14 +652,14 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
                                                            uint32_t tiles_per_xcd, int remap, int shift, Key flip, uint32_t mask,
                                                            uint32_t* __restrict__ next_counts, int next_shift,
                                                            const uint32_t* __restrict__ globsum, Key lo, Key mul,
-                                                           const Key* __restrict__ splitters, uint32_t nsplit)
+                                                           SplitSet<Key> split)
 {
     using L = ReorderLayout<Key, THREADS, KPT>;
     static_assert(!(RANGED && LOOKAHEAD), "the ranged bucket function is for the one-pass partition only");
     auto dig = [=](Key key) -> uint32_t {
         if constexpr (RANGED) {
-            if (nsplit) {
-                return splitter_bucket(static_cast<Key>(key ^ flip), splitters, nsplit);
+            if (split.n) {
+                return splitter_bucket(static_cast<Key>(key ^ flip), split);
             }
             return ranged_bucket(static_cast<Key>((key ^ flip) - lo), shift, mul, mask);
         } else {
@@ -798,9 +808,30 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
     uint32_t slot[KPT];      // first: rank among the thread's own equal-digit keys; later: tile-local slot
     // 16-bit counter of (digit d, this thread): word [d&7][tid], half d>>3
     auto counter_index = [tid](uint32_t d) { return (((d & 7u) * THREADS + tid) << 1) + (d >> 3); };
+    // RANGED: the bucket function costs tens of instructions per key, so it is evaluated once:
+    // the thread's 16 buckets are kept as nibbles, and travel to step 5 as bytes next to the
+    // staged keys (in the counter area, which is free by then)
+    uint32_t nib[RANGED ? KPT / 8 : 1];
+    auto bucket_at = [&](int i) -> uint32_t {
+        if constexpr (RANGED) {
+            return (nib[i >> 3] >> ((i & 7) * 4)) & 15u;
+        } else {
+            return dig(k[i]);
+        }
+    };
+    if constexpr (RANGED) {
+#pragma unroll
+        for (int w = 0; w < KPT / 8; ++w) {
+            nib[w] = 0;
+        }
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            nib[i >> 3] |= dig(k[i]) << ((i & 7) * 4);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
-        const uint32_t ci = counter_index(dig(k[i]));
+        const uint32_t ci = counter_index(bucket_at(i));
         const uint32_t c = cnt16[ci];
         slot[i] = c;
         cnt16[ci] = static_cast<uint16_t>(c + 1);
@@ -846,7 +877,7 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
         uint32_t first_of_digit[KPT];
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
-            first_of_digit[i] = cnt16[counter_index(dig(k[i]))];
+            first_of_digit[i] = cnt16[counter_index(bucket_at(i))];
         }
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
@@ -855,6 +886,14 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
             xk[slot[i] + (slot[i] >> L::PADSH)] = k[i];
+        }
+        if constexpr (RANGED) {
+            __syncthreads();                 // every thread has read its counters: reuse the area
+            unsigned char* staged_bucket = reinterpret_cast<unsigned char*>(cnt);
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                staged_bucket[slot[i]] = static_cast<unsigned char>(bucket_at(i));
+            }
         }
     }
     __syncthreads();
@@ -873,7 +912,11 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
         RunBase rb[KPT];
 #pragma unroll
         for (int r = 0; r < KPT; ++r) {
-            rb[r] = runs[dig(okey[r])];
+            if constexpr (RANGED) {
+                rb[r] = runs[reinterpret_cast<const unsigned char*>(cnt)[static_cast<uint32_t>(r) * THREADS + tid]];
+            } else {
+                rb[r] = runs[dig(okey[r])];
+            }
         }
 #pragma unroll
         for (int r = 0; r < KPT; ++r) {
