@@ -175,10 +175,13 @@ def main() -> None:
         elapsed = float(t.item())
     rt = eng.timings(reset=True)
     eng.set_option(rsx.OPT_PROFILE, 1)
+    sorter.record_timeline = sharded
     for _ in range(2):
         step()
     torch.cuda.synchronize()
     rt_all = eng.timings(reset=True)
+    exchange_ms = {k: round(v, 4) for k, v in sorter.timeline_ms().items()} if sharded else None
+    sorter.record_timeline = False
     if args.no_events:
         rt = rt_all
 
@@ -190,6 +193,26 @@ def main() -> None:
             u = host_keys.view(np.uint32 if key_bytes == 4 else np.uint64)
             v = got.view(u.dtype)
             ok = ok and int(np.bitwise_xor.reduce(u)) == int(np.bitwise_xor.reduce(v)) and int(u.sum(dtype=np.uint64)) == int(v.sum(dtype=np.uint64))
+        if sharded:
+            # across ranks: rank-order concatenation is sorted (boundary keys), nothing was lost or
+            # invented (count, xor and sum of all keys before == after)
+            ui = host_keys.view(np.uint32 if key_bytes == 4 else np.uint64)
+            uo = got.view(ui.dtype)
+            m63 = (1 << 63) - 1
+            mine = [int(got.size), int(np.bitwise_xor.reduce(uo)) & m63 if got.size else 0, int(uo.sum(dtype=np.uint64)) & m63 if got.size else 0,
+                    int(host_keys.size), int(np.bitwise_xor.reduce(ui)) & m63, int(ui.sum(dtype=np.uint64)) & m63,
+                    int(got[0]) if got.size else 0, int(got[-1]) if got.size else 0]
+            if np.dtype(args.dtype).kind == "u":
+                mine[6], mine[7] = mine[6] - (1 << (key_bytes * 8 - 1)), mine[7] - (1 << (key_bytes * 8 - 1))   # fit int64, order kept
+            t = torch.tensor(mine, dtype=torch.int64, device=device)
+            rows = torch.empty(world * 8, dtype=torch.int64, device=device)
+            dist.all_gather_into_tensor(rows, t)
+            rows = rows.cpu().view(world, 8).tolist()
+            full = [r for r in rows if r[0] > 0]
+            ok = ok and sum(r[0] for r in rows) == sum(r[3] for r in rows)
+            ok = ok and (np.bitwise_xor.reduce(np.array([r[1] for r in rows], dtype=np.int64)) == np.bitwise_xor.reduce(np.array([r[4] for r in rows], dtype=np.int64)))
+            ok = ok and sum(r[2] for r in rows) & m63 == sum(r[5] for r in rows) & m63
+            ok = ok and all(a[7] <= b[6] for a, b in zip(full, full[1:]))
         if not ok:
             raise SystemExit("bench: result is not a sorted permutation of the input — refusing to report a number")
 
@@ -225,6 +248,8 @@ def main() -> None:
                                  "paste": round(rt_all.paste.avg_ms, 5), "reorder": round(rt_all.reorder.avg_ms, 5),
                                  "note": "fully instrumented steps after the timed region"},
     }
+    if exchange_ms is not None:
+        line["sharded_phases_ms"] = dict(exchange_ms, note="rank 0, device time between marks of one instrumented step after the timed region")
     if rank == 0 and not sharded and not args.no_cpu_baseline:
         m = min(1 << args.cpu_sample_log2, n)
         line["cpu_baseline"] = cpu_baseline(host_keys[:m], whole=(m == n))

@@ -287,6 +287,26 @@ class ShardedSorter:
         self.strategy = strategy
         self.last_path = None          # "local" | "top" | "split" | "range" | "equal" (for tests and logs)
         self.last_imbalance = None
+        # record_timeline: device-time marks around plan / scatter / exchange / local sort (torch
+        # events on the current stream, which must be the engine's stream); read with timeline_ms()
+        self.record_timeline = False
+        self._marks = []
+
+    def _mark(self, label):
+        if self.record_timeline:
+            import torch
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._marks.append((label, ev))
+
+    def timeline_ms(self) -> dict:
+        """Milliseconds between consecutive marks of the last sort (synchronises)."""
+        import torch
+        torch.cuda.synchronize()
+        out = {}
+        for (_, a), (label, b) in zip(self._marks, self._marks[1:]):
+            out[label] = out.get(label, 0.0) + a.elapsed_time(b)
+        return out
         if world_size > 1 and dist is None:
             raise ValueError("a torch.distributed module is required for world_size > 1")
 
@@ -296,6 +316,8 @@ class ShardedSorter:
         incoming keys.  Returns the number of keys this rank ends up with; the sorted
         keys stay inside the engine (engine.copy_result / result_device)."""
         n = keys.numel()
+        self._marks = []
+        self._mark("start")
         if self.world == 1 and not self.force_exchange:
             self.engine.sort_from(keys.data_ptr(), n, payload.data_ptr() if payload is not None else None)
             self.last_path = "local"
@@ -307,8 +329,10 @@ class ShardedSorter:
             top_shift = self.key_bits - PARTITION_BITS
             table = gather_counts(self.engine.partition_count(keys.data_ptr(), n, top_shift, PARTITION_BITS), self.world, self.dist, keys.device)
             plan, imbalance = plan_from_table(table, self.rank, self.world)
+            self._mark("count+plan")
             if imbalance <= self.max_imbalance or self.strategy == "top":
                 self.engine.partition_scatter(keys.data_ptr(), n, top_shift, PARTITION_BITS, staging.data_ptr(), pay_in, pay_st)
+                self._mark("scatter")
                 self.last_path, self.last_imbalance = "top", imbalance
                 return self._exchange_and_sort(plan, n, staging, recv, payload, staging_payload, recv_payload)
         if self.strategy == "split" or (self.strategy == "auto" and self.world <= MAX_SPLITTERS + 1):
@@ -323,11 +347,14 @@ class ShardedSorter:
             return n
         self.last_path = "range"
         shift, mul = range_buckets(lo, hi, self.key_bits)
+        self._mark("count+plan")
         offs = self.engine.partition_range(
             keys.data_ptr(), n, lo, shift, mul, staging.data_ptr(),
             payload.data_ptr() if payload is not None else None,
             staging_payload.data_ptr() if staging_payload is not None else None)
+        self._mark("scatter")
         plan = plan_exchange(offs, self.rank, self.world, self.dist, keys.device)
+        self._mark("count+plan")
         return self._exchange_and_sort(plan, n, staging, recv, payload, staging_payload, recv_payload)
 
     def _sort_by_splitters(self, keys, n, staging, recv, payload, staging_payload, recv_payload, pay_in, pay_st):
@@ -344,7 +371,9 @@ class ShardedSorter:
         table = gather_counts(counts, self.world, self.dist, keys.device)
         table = [row[:2 * len(splitters) + 1] for row in table]
         plan, imbalance = split_plan(table, self.rank, self.world)
+        self._mark("count+plan")
         self.engine.partition_scatter_split(keys.data_ptr(), n, staging.data_ptr(), pay_in, pay_st)
+        self._mark("scatter")
         self.last_path, self.last_imbalance = "split", imbalance
         return self._exchange_and_sort(plan, n, staging, recv, payload, staging_payload, recv_payload)
 
@@ -354,5 +383,7 @@ class ShardedSorter:
         self.dist.all_to_all_single(recv[:plan.n_recv], staging[:n], plan.recv, plan.send)
         if payload is not None:
             self.dist.all_to_all_single(recv_payload[:plan.n_recv], staging_payload[:n], plan.recv, plan.send)
+        self._mark("all_to_all")
         self.engine.sort_from(recv.data_ptr(), plan.n_recv, recv_payload.data_ptr() if payload is not None else None)
+        self._mark("local_sort")
         return plan.n_recv
