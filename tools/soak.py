@@ -42,6 +42,35 @@ for it in range(iters):
         ok = np.array_equal(ks, np.sort(keys, kind="stable")) and np.array_equal(ps, np.argsort(keys, kind="stable").astype(np.uint32))
     else:
         ok = np.array_equal(e.download(), np.sort(keys, kind="stable"))
+    if ok and it % 3 == 0:
+        # the multi-GPU partitions on the same keys: sampled splitters, then the top bits
+        import torch
+        signed = {"uint32": np.int32, "uint64": np.int64}.get(dt)
+        tk = torch.from_numpy(keys.view(signed) if signed else keys).cuda()
+        tp = torch.arange(n, dtype=torch.int32, device="cuda") if payload else None
+        out, pout = torch.empty_like(tk), (torch.empty_like(tp) if payload else None)
+        u = keys.view(np.uint32 if keys.dtype.itemsize == 4 else np.uint64)
+        if keys.dtype.kind == "i":
+            u = u ^ u.dtype.type(1 << (keys.dtype.itemsize * 8 - 1))
+        e.set_stream(torch.cuda.current_stream().cuda_stream)
+        samples = e.sample_keys(tk.data_ptr(), n, min(1024, n))
+        sp = sorted(set(rng.choice(np.array(samples, dtype=np.uint64), size=int(rng.integers(1, 8))).tolist()))
+        spa = np.array(sp, dtype=u.dtype)
+        d = (np.searchsorted(spa, u, side="left") + np.searchsorted(spa, u, side="right")).astype(np.int64)
+        ok = e.partition_count_split(tk.data_ptr(), n, [int(v) for v in sp]) == [int(v) for v in np.bincount(d, minlength=2 * len(sp) + 1)]
+        e.partition_scatter_split(tk.data_ptr(), n, out.data_ptr(), tp.data_ptr() if payload else None, pout.data_ptr() if payload else None)
+        torch.cuda.synchronize()
+        order = np.argsort(d, kind="stable")
+        ok = ok and np.array_equal(out.cpu().numpy().view(keys.dtype), keys[order])
+        if payload:
+            ok = ok and np.array_equal(pout.cpu().numpy().view(np.uint32), order.astype(np.uint32))
+        bits = keys.dtype.itemsize * 8
+        dtop = (u >> u.dtype.type(bits - 4)).astype(np.int64)
+        ok = ok and e.partition_count(tk.data_ptr(), n, bits - 4, 4) == [int(v) for v in np.bincount(dtop, minlength=16)]
+        e.partition_scatter(tk.data_ptr(), n, bits - 4, 4, out.data_ptr(), tp.data_ptr() if payload else None, pout.data_ptr() if payload else None)
+        torch.cuda.synchronize()
+        ok = ok and np.array_equal(out.cpu().numpy().view(keys.dtype), keys[np.argsort(dtop, kind="stable")])
+        e.set_stream(0)
     if not ok:
         print("MISMATCH", it, dt, payload, n, shape, flush=True)
         sys.exit(1)
