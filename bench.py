@@ -142,16 +142,18 @@ def main() -> None:
     # the per-phase table below comes from a fully instrumented step after it
     eng.set_option(rsx.OPT_PROFILE, 0 if args.no_events else 2)
     sorter = ShardedSorter(eng, rank, world, key_bytes * 8, dist, force_exchange=force_exchange, strategy=os.environ.get("RSX_STRATEGY", "auto"))
-    staging = recv = spay = rpay = None
+    staging = recv = spay = rpay = obuf = opay = None
     if sharded:
         staging = torch.empty_like(keys)
         recv = torch.empty(capacity, dtype=keys.dtype, device=device)
+        obuf = torch.empty(capacity, dtype=keys.dtype, device=device)       # the pipelined path sorts into this
         if args.payload:
             spay = torch.empty_like(payload)
             rpay = torch.empty(capacity, dtype=payload.dtype, device=device)
+            opay = torch.empty(capacity, dtype=payload.dtype, device=device)
 
     def step() -> int:
-        return sorter.sort(keys, staging, recv, payload, spay, rpay)
+        return sorter.sort(keys, staging, recv, payload, spay, rpay, obuf, opay)
 
     for _ in range(args.warmup):
         step()
@@ -187,7 +189,11 @@ def main() -> None:
 
     ok = True
     if not args.no_verify:
-        got = eng.download()
+        if sharded and sorter.result_in_out:
+            torch.cuda.synchronize()
+            got = obuf[:n_local].cpu().numpy().view(np.dtype(args.dtype))
+        else:
+            got = eng.download()
         ok = bool(np.all(got[:-1] <= got[1:])) and got.size == n_local
         if world == 1:
             u = host_keys.view(np.uint32 if key_bytes == 4 else np.uint64)
@@ -220,9 +226,16 @@ def main() -> None:
     ms_per_step = elapsed / args.steps * 1e3
     reorder_ms = rt.reorder.avg_ms
     launches_per_step = rt.reorder.n / max(args.steps, 1)
-    # algorithmic bytes of one reorder launch: n*(K+V) read + n*(K+V) written;
-    # with N>1 the partition pass and the local passes see ~n keys each
-    scatter_bytes = 2.0 * n_local * (key_bytes + pay_bytes)
+    # algorithmic bytes of one reorder launch: n*(K+V) read + n*(K+V) written.
+    # N>1: launches differ in size (the partition pass sees n keys, the local passes what arrived,
+    # wave by wave on the pipelined path), so the figure is bytes of all launches / time of all launches
+    passes = key_bytes * 2
+    if sharded:
+        local_passes = passes - 1 if sorter.last_path == "waves" else passes
+        scatter_bytes_per_step = 2.0 * (key_bytes + pay_bytes) * (n + local_passes * n_local)
+        scatter_bytes = scatter_bytes_per_step / launches_per_step if launches_per_step else 0.0
+    else:
+        scatter_bytes = 2.0 * n_local * (key_bytes + pay_bytes)
     achieved = scatter_bytes / (reorder_ms * 1e-3) * 1e-9 if reorder_ms > 0 else 0.0
     lg = n.bit_length() - 1 if n & (n - 1) == 0 else None
     workload = f"{'2^%d' % lg if lg is not None else n} {args.dtype}{'+u32 payload' if args.payload else ''} {kind}, 4-bit digits, {key_bytes * 2} passes"

@@ -200,6 +200,17 @@ int rsx_partition_scatter(rsx_engine* e, const void* d_keys, const uint32_t* d_p
 int rsx_sample_keys(rsx_engine* e, const void* d_keys, uint64_t n, uint32_t count, uint64_t* samples);
 int rsx_partition_count_split(rsx_engine* e, const void* d_keys, uint64_t n, const uint64_t* splitters, int nsplit, uint64_t* bucket_counts);
 int rsx_partition_scatter_split(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n, void* d_keys_out, uint32_t* d_payload_out);
+/* Wave-major partition (pipelined multi-GPU exchange; world = 1, 2, 4, 8 or 16 ranks owning k = 16/world
+ * consecutive top-nibble buckets each): bucket b = rank*k + wave is placed at position wave*world + rank,
+ * so that each of the k "waves" holds one bucket per rank, contiguous and in rank order — wave w can be
+ * exchanged with one all-to-all and sorted (all its keys at a rank share the top nibble: the last LSD
+ * pass is not needed) while wave w+1 is still in flight.  counts[16] come back in that order.
+ * rsx_sort_from_to: rsx_sort_from over passes [first_pass, last_pass) whose last pass writes to the
+ * caller's d_keys_out / d_payload_out (any alignment), e.g. at an offset inside the final array. */
+int rsx_partition_count_waves(rsx_engine* e, const void* d_keys, uint64_t n, int world, uint64_t* bucket_counts);
+int rsx_partition_scatter_waves(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n, void* d_keys_out, uint32_t* d_payload_out);
+int rsx_sort_from_to(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n, int first_pass, int last_pass, void* d_keys_out,
+                     uint32_t* d_payload_out);
 int rsx_key_range(rsx_engine* e, const void* d_keys, uint64_t n, uint64_t* lo, uint64_t* hi);
 int rsx_partition_range(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n, uint64_t lo, int shift, uint64_t mul,
                         void* d_keys_out, uint32_t* d_payload_out, uint64_t* bucket_offsets);

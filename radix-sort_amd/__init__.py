@@ -38,7 +38,7 @@ SYMBOLS = [
     "rsx_create", "rsx_destroy", "rsx_set_stream", "rsx_set_option", "rsx_get_geometry", "rsx_resize",
     "rsx_upload", "rsx_fill_pad", "rsx_download", "rsx_pin_host", "rsx_unpin_host",
     "rsx_histogram", "rsx_scan", "rsx_paste", "rsx_reorder", "rsx_sort", "rsx_sync",
-    "rsx_sort_from", "rsx_partition", "rsx_partition_count", "rsx_partition_scatter", "rsx_sample_keys", "rsx_partition_count_split", "rsx_partition_scatter_split", "rsx_key_range", "rsx_partition_range", "rsx_result_device", "rsx_copy_result", "rsx_timings",
+    "rsx_sort_from", "rsx_partition", "rsx_partition_count", "rsx_partition_scatter", "rsx_sample_keys", "rsx_partition_count_split", "rsx_partition_scatter_split", "rsx_partition_count_waves", "rsx_partition_scatter_waves", "rsx_sort_from_to", "rsx_key_range", "rsx_partition_range", "rsx_result_device", "rsx_copy_result", "rsx_timings",
 ]
 
 
@@ -131,6 +131,9 @@ def load_library() -> C.CDLL:
         "rsx_sample_keys": ([P, P, U64, C.c_uint32, C.POINTER(U64)], I),
         "rsx_partition_count_split": ([P, P, U64, C.POINTER(U64), I, C.POINTER(U64)], I),
         "rsx_partition_scatter_split": ([P, P, P, U64, P, P], I),
+        "rsx_partition_count_waves": ([P, P, U64, I, C.POINTER(U64)], I),
+        "rsx_partition_scatter_waves": ([P, P, P, U64, P, P], I),
+        "rsx_sort_from_to": ([P, P, P, U64, I, I, P, P], I),
         "rsx_key_range": ([P, P, U64, C.POINTER(U64), C.POINTER(U64)], I),
         "rsx_partition_range": ([P, P, P, U64, U64, I, U64, P, P, C.POINTER(U64)], I),
         "rsx_result_device": ([P, C.POINTER(P), C.POINTER(P)], I),
@@ -309,6 +312,23 @@ class Engine:
         self._check(self.lib.rsx_partition_scatter_split(
             self._h, C.c_void_p(d_keys), C.c_void_p(d_payload) if d_payload else None, n,
             C.c_void_p(d_keys_out), C.c_void_p(d_payload_out) if d_payload_out else None), "rsx_partition_scatter_split")
+
+    def partition_count_waves(self, d_keys: int, n: int, world: int) -> list[int]:
+        counts = (C.c_uint64 * 16)()
+        self._check(self.lib.rsx_partition_count_waves(self._h, C.c_void_p(d_keys), n, world, counts), "rsx_partition_count_waves")
+        return [int(v) for v in counts]
+
+    def partition_scatter_waves(self, d_keys: int, n: int, d_keys_out: int, d_payload: int | None = None, d_payload_out: int | None = None) -> None:
+        self._check(self.lib.rsx_partition_scatter_waves(
+            self._h, C.c_void_p(d_keys), C.c_void_p(d_payload) if d_payload else None, n,
+            C.c_void_p(d_keys_out), C.c_void_p(d_payload_out) if d_payload_out else None), "rsx_partition_scatter_waves")
+
+    def sort_from_to(self, d_keys: int, n: int, first_pass: int, last_pass: int, d_keys_out: int,
+                     d_payload: int | None = None, d_payload_out: int | None = None) -> None:
+        """Device-to-device sort over passes [first_pass, last_pass); the last pass writes to d_keys_out."""
+        self._check(self.lib.rsx_sort_from_to(
+            self._h, C.c_void_p(d_keys), C.c_void_p(d_payload) if d_payload else None, n, first_pass, last_pass,
+            C.c_void_p(d_keys_out), C.c_void_p(d_payload_out) if d_payload_out else None), "rsx_sort_from_to")
 
     def key_range(self, d_keys: int, n: int) -> tuple[int, int]:
         lo, hi = C.c_uint64(), C.c_uint64()

@@ -129,6 +129,9 @@ struct rsx_engine {
     int ref_diag = 0;                           // RSX_OPT_REF_DIAGNOSTICS
     uint64_t splitters[rsx::kMaxSplitters] = {};   // splitters of the current split partition, unsigned sort order
     uint32_t nsplit = 0;
+    uint32_t wave_rot = 0;                      // non-zero only inside the wave-major partition calls
+    void* final_keys_out = nullptr;             // rsx_sort_from_to: where the last pass writes
+    uint32_t* final_perm_out = nullptr;
     unsigned long long* range_dev = nullptr;    // per-workgroup {min, max} of rsx_key_range
     unsigned long long* range_host = nullptr;   // pinned mirror
     uint32_t* starts_dev = nullptr;             // 16 bucket starts (rsx_partition)
@@ -231,6 +234,7 @@ rsx::SplitSet<Key> split_set(const rsx_engine* e, uint32_t nsplit)
     rsx::SplitSet<Key> set{};
     for (uint32_t k = 0; k < nsplit && k < static_cast<uint32_t>(rsx::kMaxSplitters); ++k) set.s[k] = static_cast<Key>(e->splitters[k]);
     set.n = nsplit;
+    set.rot = nsplit ? 0u : e->wave_rot;
     return set;
 }
 
@@ -427,8 +431,9 @@ int sort_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext_
         RSX_TRY(hipMemsetAsync(e->counts_next, 0, static_cast<size_t>(e->ntiles(count)) * RSX_RADIX * 4, e->stream), RSX_CALCULATION_FAILED);
     }
     for (int pass = e->first_pass; pass < e->last_pass; ++pass) {
-        void* out = e->keys[dst];
-        uint32_t* pout = e->has_payload ? e->perm[dst] : nullptr;
+        const bool to_caller = e->final_keys_out && pass + 1 == e->last_pass;      // rsx_sort_from_to
+        void* out = to_caller ? e->final_keys_out : e->keys[dst];
+        uint32_t* pout = e->has_payload ? (to_caller ? e->final_perm_out : e->perm[dst]) : nullptr;
         const int shift = pass * RSX_RADIX_BITS;
         int rc;
         if (!e->lookahead) {
@@ -464,8 +469,13 @@ int sort_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext_
     if (in == e->keys[0] || in == e->keys[1]) {
         e->cur = (in == e->keys[0]) ? 0 : 1;
     }
-    e->result_keys = e->keys[e->cur];
-    e->result_perm = e->has_payload ? e->perm[e->cur] : nullptr;
+    if (e->final_keys_out) {
+        e->result_keys = e->final_keys_out;
+        e->result_perm = e->has_payload ? e->final_perm_out : nullptr;
+    } else {
+        e->result_keys = e->keys[e->cur];
+        e->result_perm = e->has_payload ? e->perm[e->cur] : nullptr;
+    }
     return RSX_OK;
 }
 
@@ -478,7 +488,7 @@ template <typename Key>
 int sort_chain(rsx_engine* e, const void* ext_keys, const uint32_t* ext_perm, uint64_t count)
 {
     // (the legacy null stream cannot be captured: PyTorch's default stream is that one)
-    const bool graphable = e->use_graph && e->profile == 0 && count > 0 && count <= kGraphMaxKeys && e->stream != nullptr;
+    const bool graphable = e->use_graph && e->profile == 0 && count > 0 && count <= kGraphMaxKeys && e->stream != nullptr && !e->final_keys_out;
     if (!graphable) return sort_chain_enqueue<Key>(e, ext_keys, ext_perm, count);
     GraphEntry key{};
     key.in = ext_keys;
@@ -961,6 +971,26 @@ int rsx_sort_from(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, 
     return RSX_BY_KEY(e, sort_chain<uint32_t>(e, d_keys, d_payload, n), sort_chain<uint64_t>(e, d_keys, d_payload, n));
 }
 
+int rsx_sort_from_to(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n, int first_pass, int last_pass, void* d_keys_out,
+                     uint32_t* d_payload_out)
+{
+    if (!e) return fail(RSX_CALCULATION_FAILED, "rsx_sort_from_to: null engine");
+    if (first_pass < 0 || last_pass > e->key_bytes * 2 || first_pass >= last_pass) return fail(RSX_CALCULATION_FAILED, "rsx_sort_from_to: pass range out of bounds");
+    if (n > 0 && !d_keys_out) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_sort_from_to: no output buffer");
+    if (e->has_payload && n > 0 && !d_payload_out) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_sort_from_to: payload engine needs a payload output buffer");
+    const int saved_first = e->first_pass, saved_last = e->last_pass;
+    e->first_pass = first_pass;
+    e->last_pass = last_pass;
+    e->final_keys_out = d_keys_out;
+    e->final_perm_out = d_payload_out;
+    const int rc = rsx_sort_from(e, d_keys, d_payload, n);
+    e->final_keys_out = nullptr;
+    e->final_perm_out = nullptr;
+    e->first_pass = saved_first;
+    e->last_pass = saved_last;
+    return rc;
+}
+
 int rsx_partition(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n, int shift, int bits, void* d_keys_out,
                   uint32_t* d_payload_out, uint64_t* bucket_offsets)
 {
@@ -1123,6 +1153,77 @@ int rsx_partition_scatter_split(rsx_engine* e, const void* d_keys, const uint32_
     }
     return with_payload ? launch_reorder_t<uint64_t, true, false, true>(e, d_keys, d_keys_out, pin, pout, n, 0, RSX_RADIX - 1, 0, false, 0ull, 0ull, e->nsplit)
                         : launch_reorder_t<uint64_t, false, false, true>(e, d_keys, d_keys_out, nullptr, nullptr, n, 0, RSX_RADIX - 1, 0, false, 0ull, 0ull, e->nsplit);
+}
+
+namespace {
+// rot such that world = 16 >> rot; -1 if world is not 1, 2, 4, 8 or 16
+int wave_rot_of(int world)
+{
+    for (int rot = 0; rot <= RSX_RADIX_BITS; ++rot) {
+        if ((RSX_RADIX >> rot) == world) return rot;
+    }
+    return -1;
+}
+}  // namespace
+
+int rsx_partition_count_waves(rsx_engine* e, const void* d_keys, uint64_t n, int world, uint64_t* bucket_counts)
+{
+    if (!e || !bucket_counts) return fail(RSX_CALCULATION_FAILED, "rsx_partition_count_waves: null argument");
+    const int rot = wave_rot_of(world);
+    if (rot < 0) return fail(RSX_CALCULATION_FAILED, "rsx_partition_count_waves: world must be 1, 2, 4, 8 or 16");
+    if (n > e->capacity) return fail(RSX_RESIZE_FAILED, "rsx_partition_count_waves: beyond capacity");
+    for (int d = 0; d < RSX_RADIX; ++d) bucket_counts[d] = 0;
+    if (n == 0) return RSX_OK;
+    if (!d_keys || !aligned16(d_keys)) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_partition_count_waves: keys must be a 16-byte aligned device pointer");
+    if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
+    const int shift = e->key_bytes * 8 - RSX_RADIX_BITS;
+    e->wave_rot = static_cast<uint32_t>(rot % RSX_RADIX_BITS);        // world 1: 16 waves of one bucket, identity order
+    const int rc = RSX_BY_KEY(e, (launch_histogram<uint32_t, true>(e, d_keys, n, shift, RSX_RADIX - 1, 0u, 0u, 0)),
+                              (launch_histogram<uint64_t, true>(e, d_keys, n, shift, RSX_RADIX - 1, 0ull, 0ull, 0)));
+    e->wave_rot = 0;
+    if (rc != RSX_OK) return rc;
+    hipLaunchKernelGGL(rsx::digit_totals_kernel, dim3(RSX_RADIX), dim3(256), 0, e->stream, e->table, static_cast<uint32_t>(e->ntiles(n)), e->range_dev);
+    RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
+    RSX_TRY(hipMemcpyAsync(e->range_host, e->range_dev, RSX_RADIX * 8, hipMemcpyDeviceToHost, e->stream), RSX_CALCULATION_FAILED);
+    RSX_TRY(hipStreamSynchronize(e->stream), RSX_CALCULATION_FAILED);
+    for (int d = 0; d < RSX_RADIX; ++d) bucket_counts[d] = e->range_host[d];
+    e->counted_keys = d_keys;
+    e->counted_n = n;
+    e->counted_shift = -2;            // marks a wave-major count
+    e->counted_bits = rot;
+    return RSX_OK;
+}
+
+int rsx_partition_scatter_waves(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n, void* d_keys_out, uint32_t* d_payload_out)
+{
+    if (!e) return fail(RSX_CALCULATION_FAILED, "rsx_partition_scatter_waves: null engine");
+    if (n == 0) {
+        e->counted_keys = nullptr;
+        return RSX_OK;
+    }
+    if (d_keys != e->counted_keys || n != e->counted_n || e->counted_shift != -2)
+        return fail(RSX_CALCULATION_FAILED, "rsx_partition_scatter_waves: must follow rsx_partition_count_waves on the same keys");
+    e->counted_keys = nullptr;
+    if (!d_keys_out || !aligned16(d_keys_out)) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_partition_scatter_waves: output must be a 16-byte aligned device pointer");
+    const bool with_payload = e->has_payload && d_payload && d_payload_out;
+    if (e->has_payload && !with_payload) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_partition_scatter_waves: payload engine needs payload buffers");
+    if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
+    int rc = launch_scan(e, n);
+    if (rc == RSX_OK) rc = launch_paste(e, n);
+    if (rc != RSX_OK) return rc;
+    const uint32_t* pin = with_payload ? d_payload : nullptr;
+    uint32_t* pout = with_payload ? d_payload_out : nullptr;
+    const int shift = e->key_bytes * 8 - RSX_RADIX_BITS;
+    e->wave_rot = static_cast<uint32_t>(e->counted_bits % RSX_RADIX_BITS);
+    if (e->key_bytes == 4) {
+        rc = with_payload ? launch_reorder_t<uint32_t, true, false, true>(e, d_keys, d_keys_out, pin, pout, n, shift, RSX_RADIX - 1, 0, false, 0u, 0u, 0)
+                          : launch_reorder_t<uint32_t, false, false, true>(e, d_keys, d_keys_out, nullptr, nullptr, n, shift, RSX_RADIX - 1, 0, false, 0u, 0u, 0);
+    } else {
+        rc = with_payload ? launch_reorder_t<uint64_t, true, false, true>(e, d_keys, d_keys_out, pin, pout, n, shift, RSX_RADIX - 1, 0, false, 0ull, 0ull, 0)
+                          : launch_reorder_t<uint64_t, false, false, true>(e, d_keys, d_keys_out, nullptr, nullptr, n, shift, RSX_RADIX - 1, 0, false, 0ull, 0ull, 0);
+    }
+    e->wave_rot = 0;
+    return rc;
 }
 
 int rsx_key_range(rsx_engine* e, const void* d_keys, uint64_t n, uint64_t* lo, uint64_t* hi)

@@ -11,6 +11,14 @@ across shards, but a most-significant-bits partition is, so the data path is:
   those bits (`rsx_partition_scatter`) and exchanged — one read less and two host syncs fewer
   than the general paths.
 
+  Pipelined fast path (1, 2, 4, 8 or 16 ranks, caller passes an output buffer): the same top-4-bit
+  buckets, but staged in WAVE-MAJOR order (`rsx_partition_count_waves` / `_scatter_waves`): rank r owns
+  buckets r*k .. r*k+k-1 (k = 16/world) and wave w holds bucket r*k+w of every rank r, contiguous and in
+  rank order.  The k waves leave as k asynchronous all-to-alls; while wave w+1 is on the links, wave w
+  — whose keys at a rank all share the top nibble — is sorted with one LSD pass fewer
+  (`rsx_sort_from_to`) straight into its place in the output.  The exchange hides behind the local
+  sort, and partition + 7 passes is the single-GPU pass count.
+
   Splitter path (the default general path, up to 8 ranks): every rank samples 1024 of its keys
   (`rsx_sample_keys`), the samples are gathered, and world-1 quantile SPLITTERS are chosen.  Keys
   are bucketed as 2 * #{splitters < key} + [key equals a splitter] (`rsx_partition_count_split` /
@@ -280,7 +288,7 @@ class ShardedSorter:
         self.max_imbalance = 1.25      # top-bit buckets are used when no rank would get more than this x its share
         # general path when the top bits do not balance: "split" (sampled splitters, <= 8 ranks),
         # "range" (equal-width buckets over the global key range), "auto" = split where possible
-        if strategy not in ("auto", "split", "range", "top"):
+        if strategy not in ("auto", "waves", "split", "range", "top"):
             raise ValueError(f"unknown strategy {strategy!r}")
         if strategy == "split" and world_size > MAX_SPLITTERS + 1:
             raise ValueError(f"the splitter path serves at most {MAX_SPLITTERS + 1} ranks")
@@ -310,12 +318,14 @@ class ShardedSorter:
         if world_size > 1 and dist is None:
             raise ValueError("a torch.distributed module is required for world_size > 1")
 
-    def sort(self, keys, staging, recv, payload=None, staging_payload=None, recv_payload=None):
+    def sort(self, keys, staging, recv, payload=None, staging_payload=None, recv_payload=None, out=None, out_payload=None):
         """keys: this rank's shard (device tensor, left untouched).
         staging: same length as keys (bucket-grouped copy).  recv: capacity for the
-        incoming keys.  Returns the number of keys this rank ends up with; the sorted
-        keys stay inside the engine (engine.copy_result / result_device)."""
+        incoming keys.  out (optional, same capacity as recv): enables the pipelined path, whose
+        result lands there.  Returns the number of keys this rank ends up with; `result_in_out`
+        says whether they are in `out` or inside the engine (engine.download / copy_result)."""
         n = keys.numel()
+        self.result_in_out = False
         self._marks = []
         self._mark("start")
         if self.world == 1 and not self.force_exchange:
@@ -324,6 +334,13 @@ class ShardedSorter:
             return n
         pay_in = payload.data_ptr() if payload is not None else None
         pay_st = staging_payload.data_ptr() if staging_payload is not None else None
+        can_pipeline = out is not None and self.world in (1, 2, 4, 8, 16) and (payload is None or out_payload is not None)
+        if self.strategy == "waves" and not can_pipeline:
+            raise ValueError("strategy 'waves' needs an output buffer and 1, 2, 4, 8 or 16 ranks")
+        if self.strategy == "waves" or (self.strategy == "auto" and can_pipeline):
+            done = self._sort_in_waves(keys, n, staging, recv, payload, staging_payload, recv_payload, out, out_payload, pay_in, pay_st)
+            if done is not None:
+                return done
         if self.strategy in ("auto", "top"):
             # fast path: buckets on the top 4 key bits, if they deal out evenly
             top_shift = self.key_bits - PARTITION_BITS
@@ -356,6 +373,54 @@ class ShardedSorter:
         plan = plan_exchange(offs, self.rank, self.world, self.dist, keys.device)
         self._mark("count+plan")
         return self._exchange_and_sort(plan, n, staging, recv, payload, staging_payload, recv_payload)
+
+    def _sort_in_waves(self, keys, n, staging, recv, payload, staging_payload, recv_payload, out, out_payload, pay_in, pay_st):
+        """Pipelined fast path; returns None (nothing moved yet) when the fixed bucket ownership
+        would leave a rank with more than max_imbalance x its share."""
+        world, k = self.world, RADIX // self.world
+        counts = self.engine.partition_count_waves(keys.data_ptr(), n, world)          # [wave * world + rank]
+        table = gather_counts(counts, world, self.dist, keys.device)                    # [source][wave * world + rank]
+        loads = [sum(row[w * world + d] for row in table for w in range(k)) for d in range(world)]
+        total = sum(loads)
+        imbalance = max(loads) / max(1.0, total / world)
+        self._mark("count+plan")
+        if imbalance > self.max_imbalance and self.strategy != "waves":
+            return None                                  # same decision on every rank: it only depends on the gathered table
+        if loads[self.rank] + 4 * k > recv.numel() or loads[self.rank] > out.numel():
+            raise RuntimeError(f"rank {self.rank}: receives {loads[self.rank]} keys but the buffers hold {recv.numel()} / {out.numel()}")
+        self.engine.partition_scatter_waves(keys.data_ptr(), n, staging.data_ptr(), pay_in, pay_st)
+        self._mark("scatter")
+        # all waves are queued on the collective stream at once; they run in order behind each other
+        pending, send_at, recv_at = [], 0, 0
+        for w in range(k):
+            send = [counts[w * world + d] for d in range(world)]
+            rcv = [table[s][w * world + self.rank] for s in range(world)]
+            n_send, n_recv = sum(send), sum(rcv)
+            recv_at = (recv_at + 3) & ~3                 # 16-byte aligned start: the sort loads 16 bytes per lane
+            works = [self.dist.all_to_all_single(recv[recv_at:recv_at + n_recv], staging[send_at:send_at + n_send], rcv, send, async_op=True)]
+            if payload is not None:
+                works.append(self.dist.all_to_all_single(recv_payload[recv_at:recv_at + n_recv], staging_payload[send_at:send_at + n_send],
+                                                         rcv, send, async_op=True))
+            pending.append((works, recv_at, n_recv))
+            send_at += n_send
+            recv_at += n_recv
+        # a wave's keys share the top nibble at this rank: the most significant LSD pass is not needed
+        passes = self.key_bits // PARTITION_BITS - 1
+        done = 0
+        for works, at, n_recv in pending:
+            for work in works:
+                if work is not None:
+                    work.wait()                          # the engine's stream waits for this wave only
+            self._mark("wait")
+            if n_recv:
+                self.engine.sort_from_to(
+                    recv[at:].data_ptr(), n_recv, 0, passes, out[done:].data_ptr(),
+                    recv_payload[at:].data_ptr() if payload is not None else None,
+                    out_payload[done:].data_ptr() if payload is not None else None)
+            self._mark("local_sort")
+            done += n_recv
+        self.last_path, self.last_imbalance, self.result_in_out = "waves", imbalance, True
+        return done
 
     def _sort_by_splitters(self, keys, n, staging, recv, payload, staging_payload, recv_payload, pay_in, pay_st):
         count = min(SAMPLES_PER_RANK, n)

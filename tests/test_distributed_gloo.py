@@ -115,6 +115,30 @@ class _CpuEngineDouble:
             self._view(d_payload_out, n, np.uint32)[:] = self._view(d_payload, n, np.uint32)[order]
         return [0] + [int(v) for v in np.cumsum(np.bincount(d, minlength=16))]
 
+    def partition_count_waves(self, d_keys, n, world):
+        u = self._biased(self._view(d_keys, n, self.dtype))
+        b = (u >> u.dtype.type(self.dtype.itemsize * 8 - 4)).astype(np.int64)
+        k = 16 // world
+        self._waves = (d_keys, n, (b % k) * world + b // k)
+        return [int(v) for v in np.bincount(self._waves[2], minlength=16)]
+
+    def partition_scatter_waves(self, d_keys, n, d_keys_out, d_payload=None, d_payload_out=None):
+        assert self._waves[:2] == (d_keys, n)
+        keys = self._view(d_keys, n, self.dtype)
+        order = np.argsort(self._waves[2], kind="stable")
+        self._view(d_keys_out, n, self.dtype)[:] = keys[order]
+        if d_payload:
+            self._view(d_payload_out, n, np.uint32)[:] = self._view(d_payload, n, np.uint32)[order]
+
+    def sort_from_to(self, d_keys, n, first_pass, last_pass, d_keys_out, d_payload=None, d_payload_out=None):
+        keys = self._view(d_keys, n, self.dtype).copy()
+        u = self._biased(keys)
+        low = u & u.dtype.type((1 << (4 * last_pass)) - 1)          # only the passes asked for
+        order = np.argsort(low, kind="stable")
+        self._view(d_keys_out, n, self.dtype)[:] = keys[order]
+        if d_payload:
+            self._view(d_payload_out, n, np.uint32)[:] = self._view(d_payload, n, np.uint32).copy()[order]
+
     def sample_keys(self, d_keys, n, count):
         u = self._biased(self._view(d_keys, n, self.dtype))
         return [int(u[(2 * i + 1) * n // (2 * count)]) for i in range(count)]
@@ -194,8 +218,17 @@ def _worker(rank, world, port, dtype, kind, with_payload, n_per_rank, q, strateg
             rpay = torch.empty(n_per_rank * world, dtype=torch.int32)
         eng = _CpuEngineDouble(dtype)
         sorter = d.ShardedSorter(eng, rank, world, np.dtype(dtype).itemsize * 8, dist, strategy=strategy)
-        n_local = sorter.sort(t_keys, staging, recv, pay, spay, rpay)
-        q.put((rank, n_local, eng.result, eng.result_payload, sorter.last_path))
+        out = opay = None
+        if strategy in ("auto", "waves"):
+            out = torch.empty_like(recv)
+            opay = torch.empty_like(rpay) if with_payload else None
+        n_local = sorter.sort(t_keys, staging, recv, pay, spay, rpay, out, opay)
+        if sorter.result_in_out:
+            res = out[:n_local].numpy().view(np.dtype(dtype)).copy()
+            res_p = opay[:n_local].numpy().view(np.uint32).copy() if with_payload else None
+        else:
+            res, res_p = eng.result, eng.result_payload
+        q.put((rank, n_local, res, res_p, sorter.last_path))
     finally:
         dist.destroy_process_group()
 
@@ -203,6 +236,8 @@ def _worker(rank, world, port, dtype, kind, with_payload, n_per_rank, q, strateg
 @pytest.mark.parametrize("dtype,kind,with_payload,strategy", [
     ("uint32", "SeededUniform", False, "auto"),
     ("int32", "SeededUniform", True, "auto"),
+    ("int64", "SeededUniform", True, "waves"),
+    ("uint32", "SeededUniform", True, "top"),
     ("uint64", "SeededUniform", True, "split"),
     ("int64", "Random", False, "auto"),       # all keys are small non-negative: top bits put them on one rank
     ("uint32", "Zeros", True, "auto"),        # every key equal: the tie bucket is cut at the shard boundary
@@ -236,8 +271,8 @@ def test_sharded_sort_world2(dtype, kind, with_payload, strategy):
     assert sum(o[1] for o in outs) == full.size
     assert np.array_equal(got, np.sort(full, kind="stable"))
     assert len({o[4] for o in outs}) == 1                          # all ranks took the same path
-    if strategy == "auto" and kind != "SeededUniform":
-        assert outs[0][4] == "split"
+    if strategy == "auto":
+        assert outs[0][4] == ("waves" if kind == "SeededUniform" else "split")
     if kind in ("Range", "InvertedRange", "SeededUniform") or strategy != "range":
         assert max(o[1] for o in outs) <= 0.6 * full.size        # the ranks stay balanced
     if with_payload:

@@ -34,7 +34,7 @@ class _RankDist:
         torch.cuda.synchronize()
         self.hub.barrier.wait()
 
-    def all_to_all_single(self, out, inp, out_splits, in_splits):
+    def all_to_all_single(self, out, inp, out_splits, in_splits, async_op=False):
         import torch
         torch.cuda.synchronize()
         self.hub.slots[self.rank] = (inp, in_splits)
@@ -66,7 +66,8 @@ def _make_full(kind, dtype, n, oracle):
     ("int32", "Range", True, 2, "auto"), ("uint64", "InvertedRange", False, 2, "auto"),
     ("int32", "Range", True, 2, "range"), ("uint64", "InvertedRange", False, 2, "range"), ("uint32", "Zeros", True, 2, "range"),
     ("uint32", "HeavyTies", True, 4, "auto"), ("int64", "HeavyTies", True, 3, "auto"), ("uint64", "Skewed", True, 4, "auto"),
-    ("int32", "Skewed", False, 4, "auto"), ("uint32", "SeededUniform", True, 4, "split"), ("uint32", "Random", False, 4, "auto")])
+    ("int32", "Skewed", False, 4, "auto"), ("uint32", "SeededUniform", True, 4, "split"), ("uint32", "Random", False, 4, "auto"),
+    ("uint64", "SeededUniform", True, 4, "waves"), ("int32", "SeededUniform", True, 2, "top"), ("uint32", "SeededUniform", False, 3, "auto")])
 def test_ranks_on_one_gpu(rsx, oracle, dtype, kind, with_payload, world, strategy):
     import torch
     from radix_sort_amd.distributed import ShardedSorter
@@ -92,8 +93,14 @@ def test_ranks_on_one_gpu(rsx, oracle, dtype, kind, with_payload, world, strateg
                 with rsx.Engine(dtype, n * world, payload=with_payload) as eng:
                     eng.set_stream(stream.cuda_stream)
                     sorter = ShardedSorter(eng, rank, world, np.dtype(dtype).itemsize * 8, hub.view(rank), strategy=strategy)
-                    n_local = sorter.sort(keys, staging, recv, pay, spay, rpay)
-                    out = eng.download(want_perm=True) if with_payload else (eng.download(), None)
+                    obuf = torch.empty_like(recv)
+                    opay = torch.empty_like(rpay) if with_payload else None
+                    n_local = sorter.sort(keys, staging, recv, pay, spay, rpay, obuf, opay)
+                    if sorter.result_in_out:
+                        torch.cuda.synchronize()
+                        out = (obuf[:n_local].cpu().numpy().view(np.dtype(dtype)), opay[:n_local].cpu().numpy().view(np.uint32) if with_payload else None)
+                    else:
+                        out = eng.download(want_perm=True) if with_payload else (eng.download(), None)
                     results[rank] = (n_local, out[0], out[1], sorter.last_path)
         except Exception as exc:   # noqa: BLE001 - surface in the main thread
             errors.append(exc)
@@ -112,7 +119,8 @@ def test_ranks_on_one_gpu(rsx, oracle, dtype, kind, with_payload, world, strateg
         assert np.array_equal(np.concatenate([r[2] for r in results]), np.argsort(full, kind="stable").astype(np.uint32))
     assert len({r[3] for r in results}) == 1
     if strategy == "auto":
-        assert results[0][3] == ("top" if kind in ("SeededUniform", "Random") else "split")
+        even = kind in ("SeededUniform", "Random")
+        assert results[0][3] == (("waves" if world in (1, 2, 4, 8, 16) else "top") if even else "split")
     if strategy != "range":
         assert max(r[0] for r in results) <= 1.2 * n             # balanced whatever the distribution
 
@@ -159,6 +167,51 @@ def test_sample_and_split_partition(rsx, oracle, dt):
             e.partition_count_split(tk.data_ptr(), n, list(range(8)))   # too many
         with pytest.raises(rsx.RadixSortError):
             e.partition_scatter_split(tk.data_ptr(), n, out.data_ptr(), pay.data_ptr(), pout.data_ptr())   # no count before it
+
+
+@pytest.mark.parametrize("dt", ["uint32", "int32", "uint64", "int64"])
+@pytest.mark.parametrize("world", [1, 2, 4, 8, 16])
+def test_wave_major_partition_and_partial_sort(rsx, oracle, dt, world):
+    """rsx_partition_count_waves / _scatter_waves / rsx_sort_from_to against numpy."""
+    import torch
+    n = 150001
+    keys = oracle.dataset("SeededUniform", dt, n, seed=world)
+    signed = {"uint32": np.int32, "uint64": np.int64}.get(np.dtype(dt).name)
+    tk = torch.from_numpy(keys.view(signed) if signed else keys).cuda()
+    pay = torch.arange(n, dtype=torch.int32, device="cuda")
+    out, pout = torch.empty_like(tk), torch.empty_like(pay)
+    bits = keys.dtype.itemsize * 8
+    u = keys.view(np.uint32 if bits == 32 else np.uint64)
+    if keys.dtype.kind == "i":
+        u = u ^ u.dtype.type(1 << (bits - 1))
+    b = (u >> u.dtype.type(bits - 4)).astype(np.int64)
+    k = 16 // world
+    pos = (b % k) * world + b // k
+    with rsx.Engine(dt, n, payload=True) as e:
+        e.set_stream(torch.cuda.current_stream().cuda_stream)
+        assert e.partition_count_waves(tk.data_ptr(), n, world) == [int(v) for v in np.bincount(pos, minlength=16)]
+        e.partition_scatter_waves(tk.data_ptr(), n, out.data_ptr(), pay.data_ptr(), pout.data_ptr())
+        torch.cuda.synchronize()
+        order = np.argsort(pos, kind="stable")
+        assert np.array_equal(out.cpu().numpy().view(keys.dtype), keys[order])
+        assert np.array_equal(pout.cpu().numpy().view(np.uint32), order.astype(np.uint32))
+        # sort all passes but the last into an odd offset of a caller buffer
+        passes = bits // 4 - 1
+        dst, pdst = torch.zeros(n + 7, dtype=tk.dtype, device="cuda"), torch.zeros(n + 7, dtype=torch.int32, device="cuda")
+        e.sort_from_to(tk.data_ptr(), n, 0, passes, dst[5:].data_ptr(), pay.data_ptr(), pdst[5:].data_ptr())
+        torch.cuda.synchronize()
+        low = u & u.dtype.type((1 << (4 * passes)) - 1)
+        order = np.argsort(low, kind="stable")
+        got = dst.cpu().numpy().view(keys.dtype)
+        assert np.array_equal(got[5:5 + n], keys[order]) and not got[:5].any() and not got[5 + n:].any()
+        assert np.array_equal(pdst.cpu().numpy().view(np.uint32)[5:5 + n], order.astype(np.uint32))
+        # the options of the engine are as before: a plain sort still runs every pass
+        e.sort_from(tk.data_ptr(), n, pay.data_ptr())
+        assert np.array_equal(e.download(), np.sort(keys))
+        with pytest.raises(rsx.RadixSortError):
+            e.partition_count_waves(tk.data_ptr(), n, 3)
+        with pytest.raises(rsx.RadixSortError):
+            e.sort_from_to(tk.data_ptr(), n, 3, 3, dst.data_ptr(), pay.data_ptr(), pdst.data_ptr())
 
 
 def test_world_size_one_is_plain_sort(rsx, oracle):
