@@ -337,11 +337,14 @@ class ShardedSorter:
         can_pipeline = out is not None and self.world in (1, 2, 4, 8, 16) and (payload is None or out_payload is not None)
         if self.strategy == "waves" and not can_pipeline:
             raise ValueError("strategy 'waves' needs an output buffer and 1, 2, 4, 8 or 16 ranks")
+        self._plain_table = None
         if self.strategy == "waves" or (self.strategy == "auto" and can_pipeline):
             done = self._sort_in_waves(keys, n, staging, recv, payload, staging_payload, recv_payload, out, out_payload, pay_in, pay_st)
             if done is not None:
                 return done
-        if self.strategy in ("auto", "top"):
+        # the counts of the wave attempt say whether dealing the top-bit buckets out unevenly could work
+        top_worth_a_try = self._plain_table is None or plan_from_table(self._plain_table, self.rank, self.world)[1] <= self.max_imbalance
+        if self.strategy == "top" or (self.strategy == "auto" and top_worth_a_try):
             # fast path: buckets on the top 4 key bits, if they deal out evenly
             top_shift = self.key_bits - PARTITION_BITS
             table = gather_counts(self.engine.partition_count(keys.data_ptr(), n, top_shift, PARTITION_BITS), self.world, self.dist, keys.device)
@@ -385,7 +388,10 @@ class ShardedSorter:
         imbalance = max(loads) / max(1.0, total / world)
         self._mark("count+plan")
         if imbalance > self.max_imbalance and self.strategy != "waves":
-            return None                                  # same decision on every rank: it only depends on the gathered table
+            # same decision on every rank: it only depends on the gathered table.  Leave the counts in
+            # plain bucket order (b = rank * k + wave) for the caller's next decision
+            self._plain_table = [[row[(b % k) * world + b // k] for b in range(RADIX)] for row in table]
+            return None
         if loads[self.rank] + 4 * k > recv.numel() or loads[self.rank] > out.numel():
             raise RuntimeError(f"rank {self.rank}: receives {loads[self.rank]} keys but the buffers hold {recv.numel()} / {out.numel()}")
         self.engine.partition_scatter_waves(keys.data_ptr(), n, staging.data_ptr(), pay_in, pay_st)
