@@ -143,6 +143,7 @@ struct rsx_engine {
 
     int profile = 0;            // 0 off, 1 every launch, 2 reorder launches (+ whole sort) only
     int xcd_remap = 1;
+    int reverse_odd = 0;                        // odd passes walk the tiles backwards (env RSX_REVERSE_ODD; measured, see the tuning log)
     int lookahead = 1;          // rsx_sort builds pass p+1's histogram inside pass p's reorder
     int small_scan = 1;         // rsx_sort: one-workgroup scan+paste for tables of <= 1024 tiles (env RSX_SMALL_SCAN)
     int fold_paste = 0;         // reorder adds globsum itself (no paste launch): measured 3 % slower, off; env RSX_FOLD_PASTE
@@ -341,7 +342,8 @@ int launch_reorder_t(rsx_engine* e, const void* in, void* out, const uint32_t* p
     Bracket b(e, PH_REORDER);
     hipLaunchKernelGGL((rsx::reorder_kernel<Key, kTileThreads, kKeysPerThread, PAYLOAD, LOOKAHEAD, RANGED>), dim3(g.blocks), dim3(kTileThreads),
                        L::BYTES, e->stream, static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->table, count,
-                       g.ntiles, g.tiles_per_xcd, e->xcd_remap, shift, flip_mask<Key>(e), mask, e->counts_next, next_shift,
+                       g.ntiles, g.tiles_per_xcd, e->xcd_remap | ((e->reverse_odd && ((shift / RSX_RADIX_BITS) & 1)) ? 2 : 0), shift, flip_mask<Key>(e), mask,
+                       e->counts_next, next_shift,
                        fold_paste ? static_cast<const uint32_t*>(e->globsum) : static_cast<const uint32_t*>(nullptr), lo, mul, split_set<Key>(e, nsplit));
     RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
     return RSX_OK;
@@ -614,6 +616,7 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
     e->last_pass = static_cast<int>(e->passes());
     for (auto& s : e->stats) stat_reset(s);
     if (const char* env = std::getenv("RSX_XCD_REMAP")) e->xcd_remap = std::atoi(env) != 0;
+    if (const char* env = std::getenv("RSX_REVERSE_ODD")) e->reverse_odd = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_LOOKAHEAD")) e->lookahead = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_GRAPH")) e->use_graph = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_SMALL_SCAN")) e->small_scan = std::atoi(env) != 0;

@@ -691,10 +691,12 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
     uint32_t* la = wtot + L::WTOT_DW + L::GBASE_DW;
 
     const uint32_t tid = threadIdx.x;
-    const uint32_t tile = tile_of_block(blockIdx.x, tiles_per_xcd, remap);
-    if (tile >= ntiles) {
+    const uint32_t slot_tile = tile_of_block(blockIdx.x, tiles_per_xcd, remap & 1);
+    if (slot_tile >= ntiles) {
         return;
     }
+    // bit 1 of `remap`: walk the tiles from the back (experiment: start with what the previous pass wrote last)
+    const uint32_t tile = (remap & 2) ? ntiles - 1 - slot_tile : slot_tile;
     const uint64_t base = static_cast<uint64_t>(tile) * TILE;
     const uint64_t left = n - base;
     const uint32_t valid = left < static_cast<uint64_t>(TILE) ? static_cast<uint32_t>(left) : static_cast<uint32_t>(TILE);
