@@ -25,30 +25,33 @@ struct RadixSortOptions {
     bool skip_cpu{false};           ///< --skip-cpu: no CPU referees (large sizes); validation uses sortedness
     bool pinned{false};             ///< --pinned: page-lock the host key/result buffers for the transfers
 
-    explicit RadixSortOptions(std::vector<std::string> args = {})
+    explicit RadixSortOptions(const std::vector<std::string>& args = {})
         : num_elements(AlgorithmParameters<float>::_NUM_MAX_INPUT_ELEMS)   // default 2^25 (src/RadixSortOptions.h:18)
     {
-        for (std::size_t i = 0; i < args.size(); ++i) {
-            const std::string& arg = args[i];
-            if (arg == "--num-elements") {
-                if (i + 1 >= args.size()) throw std::invalid_argument("--num-elements needs a value");
-                num_elements = static_cast<std::size_t>(std::stoull(args[++i]));
-            } else if (arg == "--perf-to-stdout") {
-                perf_to_stdout = true;
-            } else if (arg == "--perf-to-csv") {
-                perf_to_csv = true;
-            } else if (arg == "--perf-csv-to-stdout") {
-                perf_csv_to_stdout = true;
-            } else if (arg == "-v" || arg == "--verbose") {
-                verbose = true;
-            } else if (arg == "--with-permutation") {
-                with_permutation = true;
-            } else if (arg == "--stepwise") {
-                stepwise = true;
-            } else if (arg == "--skip-cpu") {
-                skip_cpu = true;
-            } else if (arg == "--pinned") {
-                pinned = true;
+        // switch spelling -> the flag it raises; unknown words are ignored, as in the reference
+        struct Switch {
+            const char* spelling;
+            bool RadixSortOptions::*flag;
+        };
+        static constexpr Switch kSwitches[] = {
+            {"--perf-to-stdout", &RadixSortOptions::perf_to_stdout},
+            {"--perf-to-csv", &RadixSortOptions::perf_to_csv},
+            {"--perf-csv-to-stdout", &RadixSortOptions::perf_csv_to_stdout},
+            {"-v", &RadixSortOptions::verbose},
+            {"--verbose", &RadixSortOptions::verbose},
+            {"--with-permutation", &RadixSortOptions::with_permutation},
+            {"--stepwise", &RadixSortOptions::stepwise},
+            {"--skip-cpu", &RadixSortOptions::skip_cpu},
+            {"--pinned", &RadixSortOptions::pinned},
+        };
+        for (auto it = args.begin(); it != args.end(); ++it) {
+            if (*it == "--num-elements") {
+                if (++it == args.end()) throw std::invalid_argument("--num-elements needs a value");
+                num_elements = static_cast<std::size_t>(std::stoull(*it));
+                continue;
+            }
+            for (const Switch& sw : kSwitches) {
+                if (*it == sw.spelling) this->*sw.flag = true;
             }
         }
     }
