@@ -681,7 +681,7 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
     constexpr int TILE = L::TILE;
     constexpr int VEC = KeyVec<Key>::N;
     constexpr int NV = KPT / VEC;
-    constexpr int KD = L::KD;
+    [[maybe_unused]] constexpr int KD = L::KD;      // dwords per key (only the LDS-transposition variant uses it)
 
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* xbuf = smem;
