@@ -5,21 +5,22 @@ The reference has no multi-device path ("Parallelism strategies: non
 is the capability the north-star adds.  LSD passes are not independent
 across shards, but a most-significant-bits partition is, so the data path is:
 
-  Fast path (keys that use their whole bit range, e.g. uniform random): every rank counts its
-  keys by the top 4 key bits (`rsx_partition_count`), the counts are exchanged, and if dealing
-  those 16 buckets out leaves no rank with more than 1.25x its share, the keys are grouped by
-  those bits (`rsx_partition_scatter`) and exchanged — one read less and two host syncs fewer
-  than the general paths.
+  1. Pipelined path, tried first (1, 2, 4, 8 or 16 ranks, caller passes an output buffer; keys that use
+  their whole bit range, e.g. uniform random): every rank counts its keys by the top 4 key bits in
+  WAVE-MAJOR order (`rsx_partition_count_waves`): rank r owns buckets r*k .. r*k+k-1 (k = 16/world) and
+  wave w holds bucket r*k+w of every rank r.  The counts are exchanged (`all_gather`), and if no rank
+  would receive more than 1.25x its share the keys are grouped in that order (`_scatter_waves`), so each
+  wave is contiguous and in rank order.  The k waves leave as k asynchronous all-to-alls; while wave
+  w+1 is on the links, wave w — whose keys at a rank all share the top nibble — is sorted with one LSD
+  pass fewer (`rsx_sort_from_to`) straight into its place in the output.  All but the first wave of
+  the exchange hides behind the local sorts, and partition + 7 passes is the single-GPU pass count.
 
-  Pipelined fast path (1, 2, 4, 8 or 16 ranks, caller passes an output buffer): the same top-4-bit
-  buckets, but staged in WAVE-MAJOR order (`rsx_partition_count_waves` / `_scatter_waves`): rank r owns
-  buckets r*k .. r*k+k-1 (k = 16/world) and wave w holds bucket r*k+w of every rank r, contiguous and in
-  rank order.  The k waves leave as k asynchronous all-to-alls; while wave w+1 is on the links, wave w
-  — whose keys at a rank all share the top nibble — is sorted with one LSD pass fewer
-  (`rsx_sort_from_to`) straight into its place in the output.  The exchange hides behind the local
-  sort, and partition + 7 passes is the single-GPU pass count.
+  2. Plain top-bit path (other world sizes, no output buffer, or strategy="top"): the same 16 buckets
+  in key order (`rsx_partition_count` / `rsx_partition_scatter`), dealt to the ranks as contiguous
+  ranges balanced on the global counts, ONE all-to-all, full local sort.  Also taken when dealing the
+  buckets out unevenly balances what the fixed ownership of path 1 does not.
 
-  Splitter path (the default general path, up to 8 ranks): every rank samples 1024 of its keys
+  3. Splitter path (when the top bits do not balance; up to 8 ranks): every rank samples 1024 of its keys
   (`rsx_sample_keys`), the samples are gathered, and world-1 quantile SPLITTERS are chosen.  Keys
   are bucketed as 2 * #{splitters < key} + [key equals a splitter] (`rsx_partition_count_split` /
   `rsx_partition_scatter_split`): even buckets are the open intervals between splitters and move
@@ -27,7 +28,7 @@ across shards, but a most-significant-bits partition is, so the data path is:
   split by (rank, index), which keeps the ranks balanced (and the argsort stable) even when one
   key value is most of the input (`split_plan`).
 
-  Range path (more than 8 ranks, or strategy="range"):
+  4. Range path (more than 8 ranks, or strategy="range"):
 
   0. every rank finds the min and max of its keys (`rsx_key_range`, one read) and the ranks
      agree on the global range [lo, hi] (`all_gather` of 4 words).  If lo == hi all keys are
@@ -52,7 +53,7 @@ local steps are stable).
 
 Nothing here touches the data on the host.  `engine` is the object that does the device
 work (radix_sort_amd.Engine in production); tests inject a CPU test double through the
-same three methods so the split/offset logic runs under gloo without a GPU.
+same methods so the split/offset logic runs under gloo without a GPU.
 """
 from __future__ import annotations
 
