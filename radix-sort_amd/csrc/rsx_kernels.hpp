@@ -39,6 +39,10 @@
 #ifndef RSX_DIRECT_LOAD
 #define RSX_DIRECT_LOAD 1
 #endif
+// 1: digits are extracted with v_bfe_u32 (one instruction) instead of shift + and
+#ifndef RSX_DIGIT_BFE
+#define RSX_DIGIT_BFE 1
+#endif
 
 namespace rsx {
 
@@ -74,6 +78,21 @@ __device__ __forceinline__ uint32_t digit_of(Key key, int shift, Key flip, uint3
     // `key + OFFSET` with OFFSET = -numeric_limits<T>::min() (RadixSortGPU.cpp:436-440,
     // RadixSort.cl:51) is exactly an XOR of the sign bit.
     return static_cast<uint32_t>((key ^ flip) >> shift) & mask;
+}
+
+// The 4-bit digit of the sort passes (mask 15 known at compile time).  32-bit keys: one v_bfe_u32 with
+// a literal width instead of shift + and.  (With the width in a register the instruction needs a
+// second VGPR operand — the constant bus takes one scalar — and the fused kernel, which sits exactly
+// at its 96-VGPR budget, spills: measured 3 % slower.  64-bit keys keep the plain route.)
+template <typename Key>
+__device__ __forceinline__ uint32_t digit4_of(Key key, int shift, Key flip)
+{
+#if RSX_DIGIT_BFE
+    if constexpr (sizeof(Key) == 4) {
+        return __builtin_amdgcn_ubfe(static_cast<uint32_t>(key ^ flip), static_cast<uint32_t>(shift), 4u);
+    }
+#endif
+    return static_cast<uint32_t>((key ^ flip) >> shift) & static_cast<uint32_t>(kRadix - 1);
 }
 
 // Bucket of the multi-GPU partition pass: x = (key ^ sign) - lo, 16 equal-width buckets over the
@@ -674,6 +693,8 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
             }
             const uint32_t b = ranged_bucket(static_cast<Key>((key ^ flip) - lo), shift, mul, mask);
             return split.rot ? wave_major(b, split.rot) : b;
+        } else if constexpr (LOOKAHEAD) {
+            return digit4_of(key, shift, flip);          // only rsx_sort's passes run the fused variant: mask is 15
         } else {
             return digit_of(key, shift, flip, mask);
         }
@@ -938,7 +959,7 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
             g[r] = rb[r].gbase + i;
             if constexpr (LOOKAHEAD) {
                 la_idx[r] = (dig(okey[r]) << 5) + (((g[r] >> L::TILE_SHIFT) - rb[r].run_tile) << 4) +
-                            digit_of(okey[r], next_shift, flip, static_cast<uint32_t>(kRadix - 1));
+                            digit4_of(okey[r], next_shift, flip);
             }
         }
     }
@@ -989,7 +1010,11 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
     }
     if constexpr (LOOKAHEAD) {
         __syncthreads();
-        for (uint32_t c = tid; c < kLaDummy; c += THREADS) {
+        // an opaque copy of the thread id: otherwise the compiler shares `tid >> 5` address arithmetic with
+        // the ranking phase, keeps it alive through the whole kernel and spills it at the 96-VGPR budget
+        uint32_t first = tid;
+        asm volatile("" : "+v"(first));
+        for (uint32_t c = first; c < kLaDummy; c += THREADS) {
             const uint32_t v = la[c];
             if (v) {
                 const uint32_t d = c >> 5, seg = (c >> 4) & 1u, d2 = c & 15u;
