@@ -67,7 +67,10 @@ def _make_full(kind, dtype, n, oracle):
     ("int32", "Range", True, 2, "range"), ("uint64", "InvertedRange", False, 2, "range"), ("uint32", "Zeros", True, 2, "range"),
     ("uint32", "HeavyTies", True, 4, "auto"), ("int64", "HeavyTies", True, 3, "auto"), ("uint64", "Skewed", True, 4, "auto"),
     ("int32", "Skewed", False, 4, "auto"), ("uint32", "SeededUniform", True, 4, "split"), ("uint32", "Random", False, 4, "auto"),
-    ("uint64", "SeededUniform", True, 4, "waves"), ("int32", "SeededUniform", True, 2, "top"), ("uint32", "SeededUniform", False, 3, "auto")])
+    ("uint64", "SeededUniform", True, 4, "waves"), ("int32", "SeededUniform", True, 2, "top"), ("uint32", "SeededUniform", False, 3, "auto"),
+    # the driver's scaling run is 8 ranks: two pipelined waves; seven splitters when the top bits do not balance
+    ("uint32", "SeededUniform", False, 8, "auto"), ("int64", "SeededUniform", True, 8, "auto"), ("uint32", "HeavyTies", True, 8, "auto"),
+    ("uint64", "Skewed", False, 8, "auto"), ("int32", "Range", True, 8, "auto"), ("uint32", "Zeros", True, 8, "auto")])
 def test_ranks_on_one_gpu(rsx, oracle, dtype, kind, with_payload, world, strategy):
     import torch
     from radix_sort_amd.distributed import ShardedSorter
@@ -122,7 +125,7 @@ def test_ranks_on_one_gpu(rsx, oracle, dtype, kind, with_payload, world, strateg
         even = kind in ("SeededUniform", "Random")
         assert results[0][3] == (("waves" if world in (1, 2, 4, 8, 16) else "top") if even else "split")
     if strategy != "range":
-        assert max(r[0] for r in results) <= 1.2 * n             # balanced whatever the distribution
+        assert max(r[0] for r in results) <= 1.25 * n            # balanced whatever the distribution
 
 
 @pytest.mark.parametrize("dt", ["uint32", "int32", "uint64", "int64"])
