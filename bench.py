@@ -7,15 +7,29 @@ One "step" = one complete sort of the resident input (all 8 passes for uint32: p
 histogram -> scan -> paste -> reorder).  At N=1 the workload is BASELINE.json configs[1]:
 2^28 uint32 keys from the reference's `Random` generator (Dataset.h:110-120), 4-bit
 digits.  Inputs are resident in HBM before the timed region; nothing crosses PCIe inside
-it.  For N>1 (launched by torch.distributed.run, one rank per GPU over RCCL) every rank
-holds 2^28 keys (weak scaling) and a step is: partition by top bits -> bucket-count
-all_gather -> all_to_all of keys over xGMI -> local sort (radix-sort_amd/distributed.py).
+it.  For N>1 the default workload is BASELINE.json configs[3]: 2^30 uint32 keys in total,
+2^30/N per GPU (`--log2-keys K` instead fixes 2^K keys PER GPU: weak scaling), and a step
+is: partition by top bits -> bucket-count all_gather ("histogram all-to-all") ->
+all_to_all of keys over xGMI -> local sort (radix-sort_amd/distributed.py), one rank per
+GPU over RCCL.
+
+`python bench.py --gpus N` from a plain shell starts the N ranks itself: the parent makes
+no GPU call, launches `python -m torch.distributed.run --nproc-per-node N bench.py ...` as
+a CHILD process on a free port, relays rank 0's JSON line and exits with the child's
+return code.  Under an external torch.distributed.run (WORLD_SIZE already set) it is a rank.
 
 Rank 0 prints ONE JSON line.  `roofline` is the reorder (scatter) kernel: algorithmic
 bytes 2*n*(K+V) per launch over its mean launch time, measured live with HIP events on the
 launch stream inside the timed region.  `cpu_baseline` is the reference's own
 RadixSortCPU (oracle/_ref, kind "reference") or this repo's restatement (kind "port")
-timed single-threaded on a bounded sample on this host.
+timed single-threaded on a bounded sample on this host (rank 0).  At N=1 the sample is the
+whole workload and the array it sorted is then compared, key for key, with the GPU's
+output (`config.verified`).  At N>1 the ranks' outputs are gathered on rank 0 and compared
+with a host sort of all the inputs.
+
+RSX_BENCH_REHEARSAL=1 (tests only) swaps the device side for the CPU test double of
+tests/_bench_rehearsal.py under gloo, so that the launcher and every line of the N>1 rank
+logic can be run on a machine without GPUs; its line says so and carries no value.
 """
 from __future__ import annotations
 
@@ -34,6 +48,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E datasheet peak (/opt/skills/guides/MI355X_MICROARCH.md)
 KIND_CODES = {"Zeros": 0, "Range": 1, "InvertedRange": 2, "Random": 3, "RandomDistributed": 4}
 DTYPE_CODES = {"uint32": 0, "int32": 1, "uint64": 2, "int64": 3}
+METRIC = "Mkeys/s + scatter-pass HBM GB/s (% of peak), 2^28 uint32 keys"
+BASE_SEED = 0x5EEDCAFEF00D
 
 
 def make_input(kind: str, dtype: str, n: int, seed: int) -> np.ndarray:
@@ -54,19 +70,22 @@ def torch_view(t_np: np.ndarray):
     return torch.from_numpy(t_np.view(signed) if signed else t_np)
 
 
-def cpu_baseline(sample: np.ndarray, whole: bool) -> dict:
-    """Reference oracle timed like SortDataRadix (copy-in + sort), 1 thread (checker only)."""
+def cpu_baseline(sample: np.ndarray, whole: bool):
+    """Reference oracle timed like SortDataRadix (copy-in + sort), 1 thread (checker only).
+    Returns (json entry, the sorted sample)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from _oracle import Oracle, RefOracle
     if RefOracle.available():
-        ms, kind = RefOracle().time_radix_sort(sample, iters=1), "reference"
+        (ms, ordered), kind = RefOracle().time_radix_sort(sample, iters=1, return_sorted=True), "reference"
     else:
-        ms, kind = Oracle().time_radix_sort(sample, iters=1), "port"
-    return {
+        (ms, ordered), kind = Oracle().time_radix_sort(sample, iters=1, return_sorted=True), "port"
+    lg = sample.size.bit_length() - 1
+    entry = {
         "value": round(sample.size / ms * 1e-3, 3), "unit": "Mkeys/s", "cores": 1, "kind": kind,
-        "sample": f"first 2^{int(np.log2(sample.size))} keys of the same input ({'the whole workload' if whole else 'a prefix'}), 1 iteration of copy-in + RadixSortCPU "
-                  f"({ms:.0f} ms); host has {os.cpu_count()} logical cores",
+        "sample": f"first {'2^%d' % lg if sample.size == 1 << lg else sample.size} keys of rank 0's input ({'the whole single-GPU workload' if whole else 'a prefix'}), "
+                  f"1 iteration of copy-in + RadixSortCPU ({ms:.0f} ms); host has {os.cpu_count()} logical cores",
     }
+    return entry, ordered
 
 
 def load_traffic(workload: str):
@@ -79,21 +98,62 @@ def load_traffic(workload: str):
         return None
 
 
-def main() -> None:
+def free_port() -> int:
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def launch_ranks(n_gpus: int, script: str | None = None, argv: list[str] | None = None) -> int:
+    """Start the N ranks as children (one torch.distributed.run process, which forks the ranks) and
+    relay their output: rank 0's JSON line to stdout, everything else to stderr.  This process never
+    touches HIP — the children are ordinary subprocesses, not an exec of a process that has
+    initialised the GPU.  Returns the children's exit code (non-zero if any rank failed)."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), script or os.path.abspath(__file__)] + (sys.argv[1:] if argv is None else argv)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env, cwd=ROOT)
+    line = None
+    for out in proc.stdout:
+        if out.startswith("{") and '"metric"' in out:
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if rc == 0 and line is None:
+        sys.stderr.write("bench: the ranks exited cleanly but rank 0 printed no result line\n")
+        rc = 1
+    if line is not None and rc == 0:
+        print(line, flush=True)
+    return rc
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--log2-keys", type=int, default=28, help="keys per GPU = 2^this")
+    ap.add_argument("--log2-keys", type=int, default=None, help="keys PER GPU = 2^this (default 28 at N=1; at N>1 the default is --total-log2-keys 30)")
+    ap.add_argument("--total-log2-keys", type=int, default=None, help="total keys over all GPUs = 2^this (default 30 = BASELINE config 4 at N>1)")
     ap.add_argument("--dtype", default="uint32", choices=list(DTYPE_CODES))
     ap.add_argument("--payload", action="store_true", help="carry a uint32 payload (h_Permut)")
     ap.add_argument("--dataset", default="Random", choices=list(KIND_CODES))
-    ap.add_argument("--total-log2-keys", type=int, default=None, help="total keys over all GPUs = 2^this (e.g. 30 for BASELINE config 4); overrides --log2-keys")
-    ap.add_argument("--cpu-sample-log2", type=int, default=28, help="CPU baseline sample = first 2^this keys of the input (2^28 ~ 13 s of RadixSortCPU)")
+    ap.add_argument("--cpu-sample-log2", type=int, default=None, help="CPU baseline sample = first 2^this keys of rank 0's input (default: 28 at N=1 = the whole workload, ~13 s; 26 at N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-verify-full", action="store_true", help="N>1: skip the gather of all outputs on rank 0 and keep only the checksum / boundary checks")
     ap.add_argument("--no-events", action="store_true", help="no HIP events inside the timed region (roofline then comes from the instrumented steps after it)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def main() -> None:
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))     # parent: no GPU call has been made in this process
 
     import torch
     import __graft_entry__ as entry
@@ -103,41 +163,63 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    dist = None
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}, or let bench.py start the ranks itself")
+    rehearsal = os.environ.get("RSX_BENCH_REHEARSAL", "0") == "1"       # tests only: CPU test double under gloo
     force_exchange = os.environ.get("RSX_FORCE_EXCHANGE", "0") == "1"   # 1 rank, but through RCCL
     sharded = world > 1 or force_exchange
-    if world > 1 or force_exchange:
+    dist = None
+    if rehearsal:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import _bench_rehearsal as reh
+        device = torch.device("cpu")
+        sync = lambda: None     # noqa: E731
+    else:
+        device = torch.device("cuda", local_rank)
+        torch.cuda.set_device(device)
+        sync = torch.cuda.synchronize
+    if sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    device = torch.device("cuda", local_rank)
-    torch.cuda.set_device(device)
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
+    # N=1: BASELINE config 2 (2^28 keys).  N>1: BASELINE config 4 (2^30 keys over all GPUs) unless a
+    # per-GPU size is asked for, which makes it a weak-scaling run.
+    if args.total_log2_keys is None and args.log2_keys is None:
+        if world > 1:
+            args.total_log2_keys = 30
+        else:
+            args.log2_keys = 28
     if args.total_log2_keys is not None:
         if (1 << args.total_log2_keys) % world:
             raise SystemExit("--total-log2-keys: total must divide evenly over the ranks")
         n = (1 << args.total_log2_keys) // world
+        scaling = "strong"
     else:
         n = 1 << args.log2_keys
+        scaling = "weak"
     key_bytes = np.dtype(args.dtype).itemsize
     pay_bytes = 4 if args.payload else 0
     # N=1: the reference's Random generator.  N>1: independent per-rank streams of the
     # seeded uniform generator (Random's fixed seed would give every rank the same shard).
     kind = args.dataset if not sharded else ("RandomDistributed" if args.dataset == "Random" else args.dataset)
-    seed = 0x5EEDCAFEF00D + rank
-    host_keys = make_input(kind, args.dtype, n, seed)
+    host_keys = make_input(kind, args.dtype, n, BASE_SEED + rank)
     keys = torch_view(host_keys).to(device)
     payload = torch.arange(n, dtype=torch.int32, device=device) if args.payload else None
 
     from radix_sort_amd.distributed import ShardedSorter
     capacity = 2 * n if sharded else n
-    eng = rsx.Engine(args.dtype, capacity, payload=args.payload, device=local_rank)
-    # a real (non-null) stream: sorts, RCCL collectives and the engine's HIP events all live on it
-    stream = torch.cuda.Stream(device=device)
-    torch.cuda.set_stream(stream)
-    eng.set_stream(stream.cuda_stream)
+    if rehearsal:
+        eng = reh.RehearsalEngine(args.dtype)
+    else:
+        eng = rsx.Engine(args.dtype, capacity, payload=args.payload, device=local_rank)
+        # a real (non-null) stream: sorts, RCCL collectives and the engine's HIP events all live on it
+        stream = torch.cuda.Stream(device=device)
+        torch.cuda.set_stream(stream)
+        eng.set_stream(stream.cuda_stream)
     # timed region: HIP events bracket only the graded reorder launches (8 pairs per sort);
     # the per-phase table below comes from a fully instrumented step after it
     eng.set_option(rsx.OPT_PROFILE, 0 if args.no_events else 2)
@@ -157,17 +239,17 @@ def main() -> None:
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+    sync()
     eng.timings(reset=True)
 
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     n_local = n
     for _ in range(args.steps):
         n_local = step()
-    torch.cuda.synchronize()
+    sync()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -177,28 +259,41 @@ def main() -> None:
         elapsed = float(t.item())
     rt = eng.timings(reset=True)
     eng.set_option(rsx.OPT_PROFILE, 1)
-    sorter.record_timeline = sharded
+    sorter.record_timeline = sharded and not rehearsal
     for _ in range(2):
         step()
-    torch.cuda.synchronize()
+    sync()
     rt_all = eng.timings(reset=True)
-    exchange_ms = {k: round(v, 4) for k, v in sorter.timeline_ms().items()} if sharded else None
+    exchange_ms = {k: round(v, 4) for k, v in sorter.timeline_ms().items()} if sorter.record_timeline else ({} if sharded else None)
     sorter.record_timeline = False
     if args.no_events:
         rt = rt_all
 
-    ok = True
+    # ---- CPU baseline (rank 0; the other ranks wait for it in the collectives below) -------------------
+    base_entry = base_sorted = None
+    if rank == 0 and not args.no_cpu_baseline:
+        lg = args.cpu_sample_log2 if args.cpu_sample_log2 is not None else (28 if world == 1 else 26)
+        m = min(1 << lg, n)
+        base_entry, base_sorted = cpu_baseline(host_keys[:m], whole=(m == n and world == 1))
+
+    # ---- verification --------------------------------------------------------------------------------
+    verified = False
     if not args.no_verify:
         if sharded and sorter.result_in_out:
-            torch.cuda.synchronize()
+            sync()
             got = obuf[:n_local].cpu().numpy().view(np.dtype(args.dtype))
         else:
             got = eng.download()
         ok = bool(np.all(got[:-1] <= got[1:])) and got.size == n_local
+        verified = "ascending permutation of the input (xor and sum checksums)"
         if world == 1:
             u = host_keys.view(np.uint32 if key_bytes == 4 else np.uint64)
             v = got.view(u.dtype)
             ok = ok and int(np.bitwise_xor.reduce(u)) == int(np.bitwise_xor.reduce(v)) and int(u.sum(dtype=np.uint64)) == int(v.sum(dtype=np.uint64))
+            if base_sorted is not None and base_sorted.size == got.size:
+                # the array the CPU baseline just sorted with RadixSortCPU, key for key (src/CRadixSortTask.cpp:225-252)
+                ok = ok and bool(np.array_equal(got, base_sorted))
+                verified = f"bit-exact vs RadixSortCPU ({base_entry['kind']}), all {got.size} keys"
         if sharded:
             # across ranks: rank-order concatenation is sorted (boundary keys), nothing was lost or
             # invented (count, xor and sum of all keys before == after)
@@ -219,8 +314,31 @@ def main() -> None:
             ok = ok and (np.bitwise_xor.reduce(np.array([r[1] for r in rows], dtype=np.int64)) == np.bitwise_xor.reduce(np.array([r[4] for r in rows], dtype=np.int64)))
             ok = ok and sum(r[2] for r in rows) & m63 == sum(r[5] for r in rows) & m63
             ok = ok and all(a[7] <= b[6] for a, b in zip(full, full[1:]))
+            verified = "ascending across ranks, permutation of the input (count, xor and sum checksums)"
+            if not args.no_verify_full and n * world <= (1 << 31):
+                # every rank's output to rank 0 (padded to the common capacity), which compares the
+                # concatenation with a host sort of ALL the inputs, key for key
+                src = obuf if sorter.result_in_out else torch_view(np.concatenate([got, np.zeros(capacity - got.size, dtype=got.dtype)])).to(device)
+                sync()
+                parts = [torch.empty(capacity, dtype=keys.dtype, device=device) for _ in range(world)] if rank == 0 else None
+                if world > 1:
+                    dist.gather(src[:capacity].contiguous(), parts, dst=0)
+                else:
+                    parts = [src]
+                flag = torch.ones(1, dtype=torch.int64, device=device)
+                if rank == 0:
+                    sizes = [r[0] for r in rows]
+                    cat = np.concatenate([p[:sz].cpu().numpy() for p, sz in zip(parts, sizes)]).view(np.dtype(args.dtype))
+                    del parts
+                    everything = np.concatenate([host_keys] + [make_input(kind, args.dtype, n, BASE_SEED + r) for r in range(1, world)])
+                    everything.sort(kind="stable")
+                    flag[0] = int(np.array_equal(cat, everything))
+                    del cat, everything
+                dist.broadcast(flag, src=0)
+                ok = ok and bool(flag.item())
+                verified = f"bit-exact vs a host sort of all {n * world} keys, gathered on rank 0"
         if not ok:
-            raise SystemExit("bench: result is not a sorted permutation of the input — refusing to report a number")
+            raise SystemExit("bench: the result is not the sorted input — refusing to report a number")
 
     total_keys = n * world
     ms_per_step = elapsed / args.steps * 1e3
@@ -237,20 +355,26 @@ def main() -> None:
     else:
         scatter_bytes = 2.0 * n_local * (key_bytes + pay_bytes)
     achieved = scatter_bytes / (reorder_ms * 1e-3) * 1e-9 if reorder_ms > 0 else 0.0
-    lg = n.bit_length() - 1 if n & (n - 1) == 0 else None
-    workload = f"{'2^%d' % lg if lg is not None else n} {args.dtype}{'+u32 payload' if args.payload else ''} {kind}, 4-bit digits, {key_bytes * 2} passes"
+
+    def pow2(v):
+        return f"2^{v.bit_length() - 1}" if v & (v - 1) == 0 else str(v)
+    workload = f"{pow2(n)} {args.dtype}{'+u32 payload' if args.payload else ''} {kind}, 4-bit digits, {passes} passes"
+    if world > 1:
+        workload = f"{pow2(total_keys)} {args.dtype}{'+u32 payload' if args.payload else ''} keys sharded {world}x ({pow2(n)} per GPU, {kind}), RCCL histogram all-gather + key all-to-all over xGMI, 4-bit digits"
+        if total_keys == 1 << 30 and args.dtype == "uint32" and not args.payload:
+            workload += " [BASELINE config 4]"
     line = {
-        "metric": "Mkeys/s + scatter-pass HBM GB/s (% of peak), 2^28 uint32 keys",
+        "metric": METRIC,
         "value": round(total_keys / (elapsed / args.steps) * 1e-6, 1),
         "unit": "Mkeys/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": {"uint32": "u32", "int32": "i32", "uint64": "u64", "int64": "i64"}[args.dtype],
         "data": "synthetic",
         "config": {"workload": workload, "keys_per_gpu": n, "total_keys": total_keys,
                    "parallelism": "single GPU" if not sharded else f"msd-partition[{sorter.last_path}] x{world} + all_to_all (RCCL) + local LSD sort",
-                   "verified": ok},
+                   "verified": verified},
         "roofline": {
             "bound": "hbm", "kernel": "reorder_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": load_traffic(workload),
@@ -263,13 +387,17 @@ def main() -> None:
     }
     if exchange_ms is not None:
         line["sharded_phases_ms"] = dict(exchange_ms, note="rank 0, device time between marks of one instrumented step after the timed region")
-    if rank == 0 and not sharded and not args.no_cpu_baseline:
-        m = min(1 << args.cpu_sample_log2, n)
-        line["cpu_baseline"] = cpu_baseline(host_keys[:m], whole=(m == n))
+    if base_entry is not None:
+        line["cpu_baseline"] = base_entry
+    if rehearsal:
+        line["metric"] = "REHEARSAL on a CPU test double (tests only) — not a measurement; " + METRIC
+        line["value"] = None
+        line["rehearsal"] = True
     if rank == 0:
         print(json.dumps(line), flush=True)
     eng.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -120,6 +120,7 @@ const char* rsx_version(void);
 int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int has_payload, uint64_t capacity);
 int rsx_destroy(rsx_engine* e);
 int rsx_set_stream(rsx_engine* e, void* hip_stream);
+int rsx_get_stream(const rsx_engine* e, void** hip_stream);   /* the hipStream_t every call of this engine is enqueued on */
 int rsx_set_option(rsx_engine* e, int option, int64_t value);
 int rsx_get_geometry(const rsx_engine* e, rsx_geometry* out);
 
@@ -171,6 +172,13 @@ int rsx_sync(rsx_engine* e);   /* CommandQueue.finish() */
  *   external keys into caller-provided output buffers; bucket_offsets receives
  *   (1<<bits)+1 exclusive offsets.  This is the bucket-grouping step of the
  *   multi-GPU exchange.  Synchronises the stream before returning. */
+/* Aliasing: d_keys may be the start of one of the engine's own two key buffers (the pointer
+ * rsx_result_device returns; with a payload engine d_payload must then be the matching payload
+ * buffer) — the sort then runs through the internal ping-pong, as rsx_sort does.  Any other overlap of
+ * the input with the engine's buffers, of rsx_sort_from_to's output with them, or of input and output
+ * with each other is refused with RSX_HOST_BUFFERS_FAILED.  After rsx_sort_from_to the result lives in
+ * the caller's buffer only: rsx_download / rsx_copy_result of keys fail and rsx_result_device yields NULL
+ * until the next sort or upload. */
 int rsx_sort_from(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n);
 int rsx_partition(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n,
                   int shift, int bits, void* d_keys_out, uint32_t* d_payload_out, uint64_t* bucket_offsets);

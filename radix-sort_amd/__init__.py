@@ -35,7 +35,7 @@ OPT_PROFILE, OPT_XCD_REMAP, OPT_FIRST_PASS, OPT_LAST_PASS, OPT_LOOKAHEAD, OPT_RE
 # every symbol include/radixsort_hip.h declares (tests/test_capi_symbols.py checks the header against this)
 SYMBOLS = [
     "rsx_device_count", "rsx_device_name", "rsx_last_error", "rsx_version",
-    "rsx_create", "rsx_destroy", "rsx_set_stream", "rsx_set_option", "rsx_get_geometry", "rsx_resize",
+    "rsx_create", "rsx_destroy", "rsx_set_stream", "rsx_get_stream", "rsx_set_option", "rsx_get_geometry", "rsx_resize",
     "rsx_upload", "rsx_fill_pad", "rsx_download", "rsx_pin_host", "rsx_unpin_host",
     "rsx_histogram", "rsx_scan", "rsx_paste", "rsx_reorder", "rsx_sort", "rsx_sync",
     "rsx_sort_from", "rsx_partition", "rsx_partition_count", "rsx_partition_scatter", "rsx_sample_keys", "rsx_partition_count_split", "rsx_partition_scatter_split", "rsx_partition_count_waves", "rsx_partition_scatter_waves", "rsx_sort_from_to", "rsx_key_range", "rsx_partition_range", "rsx_result_device", "rsx_copy_result", "rsx_timings",
@@ -110,6 +110,7 @@ def load_library() -> C.CDLL:
         "rsx_create": ([C.POINTER(P), I, I, I, I, U64], I),
         "rsx_destroy": ([P], I),
         "rsx_set_stream": ([P, P], I),
+        "rsx_get_stream": ([P, C.POINTER(P)], I),
         "rsx_set_option": ([P, I, C.c_int64], I),
         "rsx_get_geometry": ([P, C.POINTER(Geometry)], I),
         "rsx_resize": ([P, U64], I),
@@ -209,6 +210,11 @@ class Engine:
 
     def set_stream(self, hip_stream: int) -> None:
         self._check(self.lib.rsx_set_stream(self._h, C.c_void_p(hip_stream)), "rsx_set_stream")
+
+    def get_stream(self) -> int:
+        s = C.c_void_p()
+        self._check(self.lib.rsx_get_stream(self._h, C.byref(s)), "rsx_get_stream")
+        return int(s.value or 0)
 
     def set_option(self, option: int, value: int) -> None:
         self._check(self.lib.rsx_set_option(self._h, option, value), "rsx_set_option")

@@ -130,6 +130,7 @@ struct rsx_engine {
     uint64_t splitters[rsx::kMaxSplitters] = {};   // splitters of the current split partition, unsigned sort order
     uint32_t nsplit = 0;
     uint32_t wave_rot = 0;                      // non-zero only inside the wave-major partition calls
+    bool result_external = false;               // the last sort wrote into the caller's buffer (rsx_sort_from_to): nothing to download
     void* final_keys_out = nullptr;             // rsx_sort_from_to: where the last pass writes
     uint32_t* final_perm_out = nullptr;
     unsigned long long* range_dev = nullptr;    // per-workgroup {min, max} of rsx_key_range
@@ -243,6 +244,7 @@ template <typename Key, bool RANGED = false>
 int launch_histogram(rsx_engine* e, const void* in, uint64_t count, int shift, uint32_t mask, Key lo = Key{0}, Key mul = Key{0}, uint32_t nsplit = 0)
 {
     if (count == 0) return RSX_OK;
+    e->counted_keys = nullptr;          // e->table is about to be overwritten: an earlier rsx_partition_count* is void
     const Grid g = grid_for(e, count);
     Bracket b(e, PH_HISTO);
     hipLaunchKernelGGL((rsx::histogram_kernel<Key, kTileThreads, kKeysPerThread, RANGED>), dim3(g.blocks), dim3(kTileThreads), 0, e->stream,
@@ -256,6 +258,7 @@ int launch_histogram(rsx_engine* e, const void* in, uint64_t count, int shift, u
 int launch_scan(rsx_engine* e, uint64_t count, bool from_counts = false, bool scan_level2 = true)
 {
     if (count == 0) return RSX_OK;
+    e->counted_keys = nullptr;          // the raw counts turn into prefixes: a pending count is consumed or void
     const uint32_t ntiles = static_cast<uint32_t>(e->ntiles(count));
     const uint32_t ngroups = (ntiles + rsx::kScanTiles - 1) / rsx::kScanTiles;
     e->globsum_live = e->globsum;
@@ -302,6 +305,7 @@ bool launch_scan_small(rsx_engine* e, uint64_t count, bool from_counts, int* rc)
 {
     const uint32_t ntiles = static_cast<uint32_t>(e->ntiles(count));
     if (!e->small_scan || count == 0 || ntiles > static_cast<uint32_t>(rsx::kSmallScanMaxTiles)) return false;
+    e->counted_keys = nullptr;
     {
         Bracket b(e, PH_SCAN);
         if (from_counts && e->scan_zeroes) {
@@ -471,6 +475,7 @@ int sort_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext_
     if (in == e->keys[0] || in == e->keys[1]) {
         e->cur = (in == e->keys[0]) ? 0 : 1;
     }
+    e->result_external = e->final_keys_out != nullptr;
     if (e->final_keys_out) {
         e->result_keys = e->final_keys_out;
         e->result_perm = e->has_payload ? e->final_perm_out : nullptr;
@@ -508,6 +513,7 @@ int sort_chain(rsx_engine* e, const void* ext_keys, const uint32_t* ext_perm, ui
             e->cur = g.end_cur;
             e->last_in = g.end_last_in;
             e->last_shift = g.end_last_shift;
+            e->result_external = false;
             e->result_keys = e->keys[e->cur];
             e->result_perm = e->has_payload ? e->perm[e->cur] : nullptr;
             return RSX_OK;
@@ -545,6 +551,27 @@ int sort_chain(rsx_engine* e, const void* ext_keys, const uint32_t* ext_perm, ui
 bool aligned16(const void* p)
 {
     return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
+}
+
+bool overlaps(const void* a, uint64_t abytes, const void* b, uint64_t bbytes)
+{
+    const uintptr_t a0 = reinterpret_cast<uintptr_t>(a), b0 = reinterpret_cast<uintptr_t>(b);
+    return a && b && abytes && bbytes && a0 < b0 + bbytes && b0 < a0 + abytes;
+}
+
+// How a caller's device range relates to one of the engine's two ping-pong buffers:
+// 0 = disjoint from both, 1 = starts exactly at buffer *which (the pointer rsx_result_device hands out), -1 = any other overlap.
+int alias_of(const void* p, uint64_t bytes, void* const bufs[2], uint64_t buf_bytes, int* which)
+{
+    for (int i = 0; i < 2; ++i) {
+        if (!bufs[i] || !overlaps(p, bytes, bufs[i], buf_bytes)) continue;
+        if (p == bufs[i]) {
+            *which = i;
+            return 1;
+        }
+        return -1;
+    }
+    return 0;
 }
 
 int bind_device(const rsx_engine* e, int status)
@@ -745,6 +772,13 @@ int rsx_set_stream(rsx_engine* e, void* hip_stream)
     return RSX_OK;
 }
 
+int rsx_get_stream(const rsx_engine* e, void** hip_stream)
+{
+    if (!e || !hip_stream) return fail(RSX_INITIALIZATION_FAILED, "rsx_get_stream: null argument");
+    *hip_stream = static_cast<void*>(e->stream);
+    return RSX_OK;
+}
+
 int rsx_set_option(rsx_engine* e, int option, int64_t value)
 {
     if (!e) return fail(RSX_INITIALIZATION_FAILED, "rsx_set_option: null engine");
@@ -809,6 +843,7 @@ int rsx_upload(rsx_engine* e, const void* host_keys, const uint32_t* host_perm, 
         }
     }
     RSX_TRY(hipStreamSynchronize(e->stream), RSX_DATA_UPLOAD_FAILED);   // "wait until end of write" (RadixSortGPU.cpp:305)
+    e->result_external = false;
     e->result_keys = e->keys[e->cur];
     e->result_perm = e->has_payload ? e->perm[e->cur] : nullptr;
     return RSX_OK;
@@ -842,6 +877,8 @@ int rsx_download(rsx_engine* e, void* host_keys_out, uint32_t* host_perm_out, ui
 {
     if (!e) return fail(RSX_DATA_DOWNLOAD_FAILED, "rsx_download: null engine");
     if (bind_device(e, RSX_DATA_DOWNLOAD_FAILED) != RSX_OK) return RSX_DATA_DOWNLOAD_FAILED;
+    if (e->result_external && e->n > 0 && (host_keys_out || host_perm_out))
+        return fail(RSX_DATA_DOWNLOAD_FAILED, "rsx_download: the last sort (rsx_sort_from_to) wrote into the caller's buffer; the engine holds no result");
     if (e->n > 0 && host_keys_out) {
         RSX_TRY(hipMemcpyAsync(host_keys_out, e->result_keys, static_cast<size_t>(e->n) * e->key_bytes, hipMemcpyDeviceToHost, e->stream),
                 RSX_DATA_DOWNLOAD_FAILED);
@@ -940,6 +977,7 @@ int rsx_reorder(rsx_engine* e, int pass)
                               launch_reorder<uint64_t>(e, e->keys[src], e->keys[dst], pin, pout, e->n, pass * RSX_RADIX_BITS, RSX_RADIX - 1));
     if (rc != RSX_OK) return rc;
     e->cur = dst;   // swap of the buffer names (RadixSortGPU.cpp:263-266)
+    e->result_external = false;
     e->result_keys = e->keys[e->cur];
     e->result_perm = e->has_payload ? e->perm[e->cur] : nullptr;
     return RSX_OK;
@@ -969,8 +1007,27 @@ int rsx_sort_from(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, 
         return fail(RSX_HOST_BUFFERS_FAILED, "rsx_sort_from: payload engine needs a 16-byte aligned payload pointer");
     if (e->first_pass >= e->last_pass) return fail(RSX_CALCULATION_FAILED, "rsx_sort_from: empty pass range");
     if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
+    if (n == 0) {
+        e->n = 0;
+        return RSX_OK;
+    }
+    // The first pass of an external sort writes into the engine's own inputKeys buffer.  A caller who hands
+    // back one of the engine's buffers (e.g. the pointer rsx_result_device returned) would have that pass read
+    // and write the same memory: such input is sorted through the internal ping-pong instead; any other
+    // overlap with the engine's buffers is refused.
+    int wk = -1, wp = -1;
+    void* const perm_bufs[2] = {e->perm[0], e->perm[1]};
+    const int ak = alias_of(d_keys, n * static_cast<uint64_t>(e->key_bytes), e->keys, e->capacity * static_cast<uint64_t>(e->key_bytes), &wk);
+    const int ap = e->has_payload ? alias_of(d_payload, n * 4, perm_bufs, e->capacity * 4, &wp) : 0;
+    if (ak < 0 || ap < 0) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_sort_from: input overlaps the engine's own buffers (only their start addresses are accepted)");
+    if (ak == 1 || ap == 1) {
+        if (e->has_payload && !(ak == 1 && ap == 1 && wk == wp))
+            return fail(RSX_HOST_BUFFERS_FAILED, "rsx_sort_from: keys and payload must name the same one of the engine's buffer pairs");
+        e->cur = wk;
+        d_keys = nullptr;            // internal ping-pong: reads keys[cur], never writes what it reads
+        d_payload = nullptr;
+    }
     e->n = n;
-    if (n == 0) return RSX_OK;
     return RSX_BY_KEY(e, sort_chain<uint32_t>(e, d_keys, d_payload, n), sort_chain<uint64_t>(e, d_keys, d_payload, n));
 }
 
@@ -981,6 +1038,14 @@ int rsx_sort_from_to(rsx_engine* e, const void* d_keys, const uint32_t* d_payloa
     if (first_pass < 0 || last_pass > e->key_bytes * 2 || first_pass >= last_pass) return fail(RSX_CALCULATION_FAILED, "rsx_sort_from_to: pass range out of bounds");
     if (n > 0 && !d_keys_out) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_sort_from_to: no output buffer");
     if (e->has_payload && n > 0 && !d_payload_out) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_sort_from_to: payload engine needs a payload output buffer");
+    for (int i = 0; i < 2 && n > 0; ++i) {
+        if (overlaps(d_keys_out, n * static_cast<uint64_t>(e->key_bytes), e->keys[i], e->capacity * static_cast<uint64_t>(e->key_bytes)) ||
+            (e->has_payload && overlaps(d_payload_out, n * 4, e->perm[i], e->capacity * 4)))
+            return fail(RSX_HOST_BUFFERS_FAILED, "rsx_sort_from_to: the output overlaps the engine's own buffers");
+    }
+    if (n > 0 && (overlaps(d_keys_out, n * static_cast<uint64_t>(e->key_bytes), d_keys, n * static_cast<uint64_t>(e->key_bytes)) ||
+                  (e->has_payload && overlaps(d_payload_out, n * 4, d_payload, n * 4))))
+        return fail(RSX_HOST_BUFFERS_FAILED, "rsx_sort_from_to: input and output overlap");
     const int saved_first = e->first_pass, saved_last = e->last_pass;
     e->first_pass = first_pass;
     e->last_pass = last_pass;
@@ -1273,8 +1338,8 @@ int rsx_partition_range(rsx_engine* e, const void* d_keys, const uint32_t* d_pay
 int rsx_result_device(rsx_engine* e, void** d_keys, uint32_t** d_payload)
 {
     if (!e) return fail(RSX_CALCULATION_FAILED, "rsx_result_device: null engine");
-    if (d_keys) *d_keys = e->result_keys;
-    if (d_payload) *d_payload = e->result_perm;
+    if (d_keys) *d_keys = e->result_external ? nullptr : e->result_keys;
+    if (d_payload) *d_payload = e->result_external ? nullptr : e->result_perm;
     return RSX_OK;
 }
 
@@ -1283,6 +1348,8 @@ int rsx_copy_result(rsx_engine* e, void* d_keys_out, uint32_t* d_payload_out)
     if (!e) return fail(RSX_DATA_DOWNLOAD_FAILED, "rsx_copy_result: null engine");
     if (bind_device(e, RSX_DATA_DOWNLOAD_FAILED) != RSX_OK) return RSX_DATA_DOWNLOAD_FAILED;
     if (e->n == 0) return RSX_OK;
+    if (e->result_external)
+        return fail(RSX_DATA_DOWNLOAD_FAILED, "rsx_copy_result: the last sort (rsx_sort_from_to) wrote into the caller's buffer; the engine holds no result");
     if (d_keys_out) {
         RSX_TRY(hipMemcpyAsync(d_keys_out, e->result_keys, static_cast<size_t>(e->n) * e->key_bytes, hipMemcpyDeviceToDevice, e->stream),
                 RSX_DATA_DOWNLOAD_FAILED);

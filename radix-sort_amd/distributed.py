@@ -92,6 +92,7 @@ def recv_splits(all_send_splits: list[list[int]], rank: int) -> list[int]:
 class ExchangePlan:
     send: list[int]
     recv: list[int]
+    loads: list[int] | None = None      # keys every rank ends up with (same list on all ranks)
 
     @property
     def n_recv(self) -> int:
@@ -141,16 +142,31 @@ def balanced_owner(global_counts: list[int], world_size: int) -> list[int]:
     return owner
 
 
-def gather_counts(counts: list[int], world_size: int, dist, device) -> list[list[int]]:
-    """[source rank][bucket] table of everybody's 16 bucket counts (one all_gather)."""
+def gather_counts(counts: list[int], world_size: int, dist, device, caps: tuple[int, int] = (0, 0)):
+    """[source rank][bucket] table of everybody's 16 bucket counts (one all_gather) and, riding in the
+    same message, every rank's (receive-buffer, output-buffer) capacity in keys — so that whether a
+    plan fits is decided from the same data on every rank (a rank that found out alone and raised
+    would leave its peers hanging in the all-to-all)."""
     if dist is None:
-        return [list(counts)]
+        return [list(counts)], [tuple(caps)]
     import torch
 
-    t = torch.tensor(counts, dtype=torch.int64, device=device)
-    gathered = torch.empty(world_size * RADIX, dtype=torch.int64, device=device)
+    t = torch.tensor(list(counts) + [int(caps[0]), int(caps[1])], dtype=torch.int64, device=device)
+    gathered = torch.empty(world_size * (RADIX + 2), dtype=torch.int64, device=device)
     dist.all_gather_into_tensor(gathered, t)
-    return gathered.cpu().view(world_size, RADIX).tolist()
+    rows = gathered.cpu().view(world_size, RADIX + 2).tolist()
+    return [r[:RADIX] for r in rows], [(r[RADIX], r[RADIX + 1]) for r in rows]
+
+
+class CapacityError(RuntimeError):
+    """Some rank's buffers cannot hold what the exchange plan sends it.  Raised by EVERY rank, before
+    any key moves (the verdict only depends on gathered data)."""
+
+
+def check_capacity(loads: list[int], caps: list[tuple[int, int]], need_out: bool, slack: int = 0) -> None:
+    for r, (load, (recv_cap, out_cap)) in enumerate(zip(loads, caps)):
+        if load + slack > recv_cap or (need_out and load > out_cap):
+            raise CapacityError(f"rank {r} would receive {load} keys but its buffers hold {recv_cap} (receive) / {out_cap} (output)")
 
 
 def plan_from_table(table: list[list[int]], rank: int, world_size: int) -> tuple[ExchangePlan, float]:
@@ -161,26 +177,20 @@ def plan_from_table(table: list[list[int]], rank: int, world_size: int) -> tuple
     sends = [[sum(row[b] for b in range(RADIX) if owner[b] == dst) for dst in range(world_size)] for row in table]
     loads = [sum(s[dst] for s in sends) for dst in range(world_size)]
     ideal = max(1.0, sum(totals) / world_size)
-    return ExchangePlan(send=sends[rank], recv=recv_splits(sends, rank)), max(loads) / ideal
+    return ExchangePlan(send=sends[rank], recv=recv_splits(sends, rank), loads=loads), max(loads) / ideal
 
 
-def plan_exchange(bucket_offsets: list[int], rank: int, world_size: int, dist, device) -> ExchangePlan:
+def plan_exchange(bucket_offsets: list[int], rank: int, world_size: int, dist, device, caps: tuple[int, int] = (0, 0)):
     """Step 2 of the module docstring ("histogram all-to-all"): all ranks learn every rank's 16
     bucket counts, deal the buckets to ranks in balanced contiguous ranges, and derive their
-    send and receive split sizes."""
-    import torch
-
+    send and receive split sizes.  Returns (plan, capacities of all ranks)."""
     counts = [bucket_offsets[b + 1] - bucket_offsets[b] for b in range(RADIX)]
     if dist is None:
         mine = send_splits(bucket_offsets, world_size)
-        return ExchangePlan(send=mine, recv=mine)
-    t = torch.tensor(counts, dtype=torch.int64, device=device)
-    gathered = torch.empty(world_size * RADIX, dtype=torch.int64, device=device)
-    dist.all_gather_into_tensor(gathered, t)
-    table = gathered.cpu().view(world_size, RADIX).tolist()              # [source rank][bucket]
-    owner = balanced_owner([sum(row[b] for row in table) for b in range(RADIX)], world_size)
-    sends = [[sum(row[b] for b in range(RADIX) if owner[b] == dst) for dst in range(world_size)] for row in table]
-    return ExchangePlan(send=sends[rank], recv=recv_splits(sends, rank))
+        return ExchangePlan(send=mine, recv=mine, loads=[sum(mine)]), [tuple(caps)]
+    table, all_caps = gather_counts(counts, world_size, dist, device, caps)   # [source rank][bucket]
+    plan, _ = plan_from_table(table, rank, world_size)
+    return plan, all_caps
 
 
 SAMPLES_PER_RANK = 1024
@@ -253,7 +263,7 @@ def split_plan(table: list[list[int]], rank: int, world_size: int) -> tuple[Exch
             pos = hi
     loads = [cuts[d + 1] - cuts[d] for d in range(world_size)]
     ideal = max(1.0, sum(totals) / world_size)
-    return ExchangePlan(send=sends[rank], recv=recv_splits(sends, rank)), max(loads) / ideal
+    return ExchangePlan(send=sends[rank], recv=recv_splits(sends, rank), loads=loads), max(loads) / ideal
 
 
 def gather_samples(samples: list[int], n_local: int, world_size: int, dist, device) -> tuple[list[list[int]], list[int]]:
@@ -278,6 +288,10 @@ class ShardedSorter:
     """Per-rank driver.  Buffers are torch tensors (device memory + RCCL plumbing)."""
 
     def __init__(self, engine, rank: int, world_size: int, key_bits: int, dist=None, force_exchange: bool = False, strategy: str = "auto"):
+        if world_size > 1 and dist is None:
+            raise ValueError("a torch.distributed module (or a stand-in with its calls) is required for world_size > 1")
+        if not 0 <= rank < world_size:
+            raise ValueError(f"rank {rank} outside world of {world_size}")
         self.engine = engine
         self.rank = rank
         self.world = world_size
@@ -316,8 +330,19 @@ class ShardedSorter:
         for (_, a), (label, b) in zip(self._marks, self._marks[1:]):
             out[label] = out.get(label, 0.0) + a.elapsed_time(b)
         return out
-        if world_size > 1 and dist is None:
-            raise ValueError("a torch.distributed module is required for world_size > 1")
+
+    def _bind_stream(self, keys) -> None:
+        """The collectives and `work.wait()` order against torch's CURRENT stream only; every device step of
+        the engine is asynchronous on the engine's stream.  The two must be the same stream or the
+        all-to-all reads `staging` before the scatter has written it.  A real engine is re-bound to the
+        current stream when it sits on another one (test doubles without streams are left alone)."""
+        get = getattr(self.engine, "get_stream", None)
+        if get is None or not getattr(keys, "is_cuda", False):
+            return
+        import torch
+        cur = torch.cuda.current_stream(keys.device).cuda_stream
+        if get() != cur:
+            self.engine.set_stream(cur)
 
     def sort(self, keys, staging, recv, payload=None, staging_payload=None, recv_payload=None, out=None, out_payload=None):
         """keys: this rank's shard (device tensor, left untouched).
@@ -328,6 +353,8 @@ class ShardedSorter:
         n = keys.numel()
         self.result_in_out = False
         self._marks = []
+        self._bind_stream(keys)
+        self._caps = (recv.numel() if recv is not None else 0, out.numel() if out is not None else 0)
         self._mark("start")
         if self.world == 1 and not self.force_exchange:
             self.engine.sort_from(keys.data_ptr(), n, payload.data_ptr() if payload is not None else None)
@@ -348,10 +375,11 @@ class ShardedSorter:
         if self.strategy == "top" or (self.strategy == "auto" and top_worth_a_try):
             # fast path: buckets on the top 4 key bits, if they deal out evenly
             top_shift = self.key_bits - PARTITION_BITS
-            table = gather_counts(self.engine.partition_count(keys.data_ptr(), n, top_shift, PARTITION_BITS), self.world, self.dist, keys.device)
+            table, caps = gather_counts(self.engine.partition_count(keys.data_ptr(), n, top_shift, PARTITION_BITS), self.world, self.dist, keys.device, self._caps)
             plan, imbalance = plan_from_table(table, self.rank, self.world)
             self._mark("count+plan")
             if imbalance <= self.max_imbalance or self.strategy == "top":
+                check_capacity(plan.loads, caps, need_out=False)
                 self.engine.partition_scatter(keys.data_ptr(), n, top_shift, PARTITION_BITS, staging.data_ptr(), pay_in, pay_st)
                 self._mark("scatter")
                 self.last_path, self.last_imbalance = "top", imbalance
@@ -374,7 +402,8 @@ class ShardedSorter:
             payload.data_ptr() if payload is not None else None,
             staging_payload.data_ptr() if staging_payload is not None else None)
         self._mark("scatter")
-        plan = plan_exchange(offs, self.rank, self.world, self.dist, keys.device)
+        plan, caps = plan_exchange(offs, self.rank, self.world, self.dist, keys.device, self._caps)
+        check_capacity(plan.loads, caps, need_out=False)
         self._mark("count+plan")
         return self._exchange_and_sort(plan, n, staging, recv, payload, staging_payload, recv_payload)
 
@@ -383,18 +412,23 @@ class ShardedSorter:
         would leave a rank with more than max_imbalance x its share."""
         world, k = self.world, RADIX // self.world
         counts = self.engine.partition_count_waves(keys.data_ptr(), n, world)          # [wave * world + rank]
-        table = gather_counts(counts, world, self.dist, keys.device)                    # [source][wave * world + rank]
+        table, caps = gather_counts(counts, world, self.dist, keys.device, self._caps)   # [source][wave * world + rank]
         loads = [sum(row[w * world + d] for row in table for w in range(k)) for d in range(world)]
         total = sum(loads)
         imbalance = max(loads) / max(1.0, total / world)
         self._mark("count+plan")
-        if imbalance > self.max_imbalance and self.strategy != "waves":
+        fits = True
+        try:
+            check_capacity(loads, caps, need_out=True, slack=4 * k)     # each wave starts 16-byte aligned in recv
+        except CapacityError:
+            if self.strategy == "waves":
+                raise                                                   # on every rank alike
+            fits = False
+        if (imbalance > self.max_imbalance and self.strategy != "waves") or not fits:
             # same decision on every rank: it only depends on the gathered table.  Leave the counts in
             # plain bucket order (b = rank * k + wave) for the caller's next decision
             self._plain_table = [[row[(b % k) * world + b // k] for b in range(RADIX)] for row in table]
             return None
-        if loads[self.rank] + 4 * k > recv.numel() or loads[self.rank] > out.numel():
-            raise RuntimeError(f"rank {self.rank}: receives {loads[self.rank]} keys but the buffers hold {recv.numel()} / {out.numel()}")
         self.engine.partition_scatter_waves(keys.data_ptr(), n, staging.data_ptr(), pay_in, pay_st)
         self._mark("scatter")
         # all waves are queued on the collective stream at once; they run in order behind each other
@@ -440,9 +474,10 @@ class ShardedSorter:
             return n
         counts = self.engine.partition_count_split(keys.data_ptr(), n, splitters)
         counts = counts + [0] * (RADIX - len(counts))
-        table = gather_counts(counts, self.world, self.dist, keys.device)
+        table, caps = gather_counts(counts, self.world, self.dist, keys.device, self._caps)
         table = [row[:2 * len(splitters) + 1] for row in table]
         plan, imbalance = split_plan(table, self.rank, self.world)
+        check_capacity(plan.loads, caps, need_out=False)
         self._mark("count+plan")
         self.engine.partition_scatter_split(keys.data_ptr(), n, staging.data_ptr(), pay_in, pay_st)
         self._mark("scatter")
@@ -450,8 +485,7 @@ class ShardedSorter:
         return self._exchange_and_sort(plan, n, staging, recv, payload, staging_payload, recv_payload)
 
     def _exchange_and_sort(self, plan, n, staging, recv, payload, staging_payload, recv_payload):
-        if plan.n_recv > recv.numel():
-            raise RuntimeError(f"rank {self.rank}: receives {plan.n_recv} keys but the receive buffer holds {recv.numel()}")
+        assert plan.n_recv <= recv.numel()      # check_capacity ran on every rank before anything moved
         self.dist.all_to_all_single(recv[:plan.n_recv], staging[:n], plan.recv, plan.send)
         if payload is not None:
             self.dist.all_to_all_single(recv_payload[:plan.n_recv], staging_payload[:n], plan.recv, plan.send)

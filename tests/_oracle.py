@@ -104,12 +104,13 @@ class Oracle:
         return k, table, globsum
 
     # -- baseline timing -----------------------------------------------------
-    def time_radix_sort(self, keys: np.ndarray, iters: int = 1) -> float:
+    def time_radix_sort(self, keys: np.ndarray, iters: int = 1, return_sorted: bool = False):
+        """Milliseconds per (copy-in + sort); with return_sorted also the array it sorted."""
         k = np.ascontiguousarray(keys)
         scratch = np.empty_like(k)
         ms = C.c_double(0.0)
         assert self.lib.oracle_time_radix_sort(_code(k.dtype), k.ctypes.data, scratch.ctypes.data, k.size, iters, C.byref(ms)) == 0
-        return ms.value
+        return (ms.value, scratch) if return_sorted else ms.value
 
     def time_std_sort(self, keys: np.ndarray, iters: int = 1) -> float:
         k = np.ascontiguousarray(keys)
@@ -148,9 +149,9 @@ class RefOracle:
         assert self.lib.ref_dataset(KINDS[kind], _code(dtype), out.ctypes.data, n) == 0
         return out
 
-    def time_radix_sort(self, keys: np.ndarray, iters: int = 1) -> float:
+    def time_radix_sort(self, keys: np.ndarray, iters: int = 1, return_sorted: bool = False):
         k = np.ascontiguousarray(keys)
         scratch = np.empty_like(k)
         ms = C.c_double(0.0)
         assert self.lib.ref_time_radix_sort(_code(k.dtype), k.ctypes.data, scratch.ctypes.data, k.size, iters, C.byref(ms)) == 0
-        return ms.value
+        return (ms.value, scratch) if return_sorted else ms.value

@@ -329,3 +329,58 @@ def test_choose_splitters_and_split_plan():
             assert plans[r].recv == [plans[s].send[r] for s in range(world)]
         cuts = d.split_cuts([sum(row[b] for row in table) for b in range(2 * m + 1)], world)
         assert cuts == sorted(cuts) and [p.n_recv for p in plans] == [cuts[i + 1] - cuts[i] for i in range(world)]
+
+
+def _overflow_worker(rank, world, port, strategy, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        d = _dist_module()
+        from _oracle import Oracle
+        n = 4000
+        full = Oracle().dataset("SeededUniform", "uint32", n * world, seed=3)
+        keys = torch.from_numpy(full[rank * n:(rank + 1) * n].copy().view(np.int32))
+        staging = torch.empty_like(keys)
+        # rank 1's receive buffer is far too small; rank 0's is generous
+        recv = torch.empty(n * world if rank == 0 else n // 4, dtype=keys.dtype)
+        out = torch.empty(n * world, dtype=keys.dtype)
+        sorter = d.ShardedSorter(_CpuEngineDouble("uint32"), rank, world, 32, dist, strategy=strategy)
+        try:
+            sorter.sort(keys, staging, recv, None, None, None, out, None)
+            q.put((rank, "no error"))
+        except d.CapacityError as exc:
+            q.put((rank, "capacity:" + str(exc)))
+        dist.barrier()          # both ranks are still in step: nobody is stuck inside an all_to_all
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("strategy", ["auto", "waves", "top", "split", "range"])
+def test_too_small_receive_buffer_raises_on_every_rank(strategy):
+    """One rank's receive buffer cannot hold its share: EVERY rank must raise before any all_to_all
+    is issued (a lone raise would leave the peers hanging in the collective)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overflow_worker, args=(r, 2, port, strategy, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(o[1].startswith("capacity:rank 1 would receive") for o in outs), outs
+
+
+def test_sorter_constructor_validates():
+    d = _dist_module()
+    with pytest.raises(ValueError):
+        d.ShardedSorter(_CpuEngineDouble("uint32"), 0, 2, 32, dist=None)
+    with pytest.raises(ValueError):
+        d.ShardedSorter(_CpuEngineDouble("uint32"), 2, 2, 32, dist=object())
+    with pytest.raises(ValueError):
+        d.ShardedSorter(_CpuEngineDouble("uint32"), 0, 1, 32, strategy="nope")

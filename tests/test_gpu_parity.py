@@ -381,6 +381,136 @@ def test_full_size_2pow28_uint64_with_payload(mod, oracle):
     assert bool(np.all(ps[ties] < ps[ties + 1]))      # stability on equal keys
 
 
+def test_full_size_2pow28_uint32_random_bit_exact_vs_oracle(mod, oracle):
+    """BASELINE config 2 at full size against the checker itself (reference: the GPU result is
+    memcmp'd with the CPU referees, src/CRadixSortTask.cpp:225-252): every one of the 2^28 output
+    keys equals RadixSortCPU's (restatement; and the reference's own headers where oracle/_ref
+    was built)."""
+    n = 1 << 28
+    keys = oracle.dataset("Random", "uint32", n)
+    got = _sort(mod, keys)
+    want = oracle.radix_sort(keys)
+    assert np.array_equal(got, want)
+    from _oracle import RefOracle
+    if RefOracle.available():
+        assert np.array_equal(got, RefOracle().radix_sort(keys))
+
+
+def test_2pow26_uint64_with_payload_bit_exact_vs_oracle(mod, oracle):
+    """BASELINE config 3's shape (uint64 keys with 64-bit entropy + uint32 payload = iota) at 2^26
+    against the oracle extended with a payload array: keys AND the permutation, bit for bit."""
+    n = 1 << 26
+    keys = oracle.dataset("SeededUniform", "uint64", n)
+    keys[1::2] = keys[0:-1:2]                       # every key twice: the payload order of ties is checked too
+    perm = np.arange(n, dtype=np.uint32)
+    ks, ps = _sort(mod, keys, perm)
+    wk, wp = oracle.radix_sort(keys, perm)
+    assert np.array_equal(ks, wk)
+    assert np.array_equal(ps, wp)
+
+
+@pytest.mark.parametrize("kind", ["Zeros", "InvertedRange", "SeededUniform", "Range"])
+def test_config5_inputs_2pow26_bit_exact_vs_oracle(mod, oracle, kind):
+    """BASELINE config 5's adversarial inputs (Dataset.h:84-137) at 2^26 against the oracle."""
+    keys = oracle.dataset(kind, "uint32", 1 << 26)
+    if kind == "Range":
+        keys[-1] = np.uint32(0xFFFFFFFF)           # keeps the oracle's round count at 8 (its domain, SURVEY 8c)
+    assert np.array_equal(_sort(mod, keys), oracle.radix_sort(keys))
+
+
+# --------------------------------------------------------------------------- aliasing and stale state
+def test_sort_from_accepts_the_engines_own_result_buffer(mod, oracle):
+    """rsx_sort_from on the pointer rsx_result_device just returned (one of the engine's ping-pong
+    buffers) must not reorder in place: it runs through the internal ping-pong.  Interior pointers
+    and outputs overlapping the engine's buffers are refused."""
+    import torch
+    n = 70001
+    keys = oracle.dataset("SeededUniform", "uint32", n)
+    t = torch.from_numpy(keys.view(np.int32)).cuda()
+    with mod.Engine("uint32", 2 * n, payload=True) as e:
+        e.set_stream(torch.cuda.current_stream().cuda_stream)
+        pay = torch.arange(n, dtype=torch.int32, device="cuda")
+        e.sort_from(t.data_ptr(), n, pay.data_ptr())
+        first_k, first_p = e.download(want_perm=True)
+        assert np.array_equal(first_k, np.sort(keys))
+        # scramble the result in place (low 12 bits descending), then sort the engine's own buffer again
+        dk, dp = e.result_device()
+        assert dk and dp
+        e.sort_from(dk, n, dp)
+        k2, p2 = e.download(want_perm=True)
+        assert np.array_equal(k2, first_k) and np.array_equal(p2, first_p)      # sorting sorted data: identical, stable
+        for _ in range(3):                                                       # and again from whichever buffer holds it now
+            dk, dp = e.result_device()
+            e.sort_from(dk, n, dp)
+        k3, p3 = e.download(want_perm=True)
+        assert np.array_equal(k3, first_k) and np.array_equal(p3, first_p)
+        dk, dp = e.result_device()
+        with pytest.raises(mod.RadixSortError) as ei:
+            e.sort_from(dk + 64, n, dp + 64)                                    # interior pointer
+        assert ei.value.status == 1
+        with pytest.raises(mod.RadixSortError):
+            e.sort_from(dk, n, pay.data_ptr())                                   # keys inside, payload outside
+        out = torch.empty(n, dtype=torch.int32, device="cuda")
+        with pytest.raises(mod.RadixSortError):
+            e.sort_from_to(t.data_ptr(), n, 0, 7, dk, pay.data_ptr(), dp)        # output = engine buffer
+        with pytest.raises(mod.RadixSortError):
+            e.sort_from_to(t.data_ptr(), n, 0, 7, t.data_ptr(), pay.data_ptr(), out.data_ptr())   # output = input
+        # after rsx_sort_from_to the engine holds no result
+        pout = torch.empty_like(out)
+        e.sort_from_to(t.data_ptr(), n, 0, 8, out.data_ptr(), pay.data_ptr(), pout.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), first_k)
+        assert e.result_device() == (0, 0)
+        with pytest.raises(mod.RadixSortError) as ei:
+            e.download()
+        assert ei.value.status == 5                                              # DATA_DOWNLOAD_FAILED
+        with pytest.raises(mod.RadixSortError):
+            e.copy_result(out.data_ptr(), pout.data_ptr())
+        e.sort_from(t.data_ptr(), n, pay.data_ptr())                             # the next sort restores it
+        assert np.array_equal(e.download(), first_k)
+
+
+def test_count_then_foreign_sort_then_scatter_is_refused(mod, oracle):
+    """rsx_partition_count leaves a raw table for exactly one input; any call that overwrites the table
+    in between (a sort, a histogram, another partition) must void it, or the scatter would scan a
+    foreign table and write out of bounds."""
+    import torch
+    n = 60000
+    a = torch.from_numpy(oracle.dataset("SeededUniform", "int32", n)).cuda()
+    b = torch.from_numpy(oracle.dataset("Random", "int32", n // 2)).cuda()
+    out = torch.empty_like(a)
+    with mod.Engine("int32", n) as e:
+        e.set_stream(torch.cuda.current_stream().cuda_stream)
+        for clobber in ("sort_from", "histogram", "partition", "count_other"):
+            e.partition_count(a.data_ptr(), n, 28, 4)
+            if clobber == "sort_from":
+                e.sort_from(b.data_ptr(), b.numel())
+            elif clobber == "histogram":
+                e.upload(b.cpu().numpy())
+                e.histogram(0)
+            elif clobber == "partition":
+                e.partition(b.data_ptr(), b.numel(), 28, 4, out.data_ptr())
+            else:
+                e.partition_count(b.data_ptr(), b.numel(), 28, 4)
+            with pytest.raises(mod.RadixSortError) as ei:
+                e.partition_scatter(a.data_ptr(), n, 28, 4, out.data_ptr())
+            assert ei.value.status == 4                                          # CALCULATION_FAILED
+        splitters = [1 << 30, 3 << 30]
+        e.partition_count_split(a.data_ptr(), n, splitters)
+        e.sort_from(b.data_ptr(), b.numel())
+        with pytest.raises(mod.RadixSortError):
+            e.partition_scatter_split(a.data_ptr(), n, out.data_ptr())
+        e.partition_count_waves(a.data_ptr(), n, 4)
+        e.sort_from(b.data_ptr(), b.numel())
+        with pytest.raises(mod.RadixSortError):
+            e.partition_scatter_waves(a.data_ptr(), n, out.data_ptr())
+        # and the guarded sequence itself still works
+        counts = e.partition_count(a.data_ptr(), n, 28, 4)
+        e.partition_scatter(a.data_ptr(), n, 28, 4, out.data_ptr())
+        torch.cuda.synchronize()
+        assert sum(counts) == n
+
+
 # --------------------------------------------------------------------------- extremes
 def test_maximum_length_2pow32_minus_1024(mod):
     """Largest length the uint32_t API admits (Resize keeps n a multiple of 1024 below 2^32): every

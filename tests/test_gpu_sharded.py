@@ -12,42 +12,83 @@ pytestmark = pytest.mark.gpu
 
 
 class _Loopback:
+    """torch.distributed's call signatures for N ranks = N threads on ONE GPU, with RCCL's stream
+    semantics and NO device-wide synchronisation: a collective runs on the rank's own communication
+    stream, starts after the `ready` events every participant recorded on its CURRENT stream at call
+    time, and a rank's current stream learns of its completion only through `work.wait()` (or, for a
+    blocking call, before the call returns).  A sorter that forgot a wait, or whose engine ran on a
+    stream other than torch's current one, therefore races here exactly as it would on 8 GPUs."""
+
     def __init__(self, world):
         self.world = world
         self.barrier = threading.Barrier(world)
         self.slots = [None] * world
+        self.done = [None] * world
 
     def view(self, rank):
         return _RankDist(self, rank)
 
 
+class _Work:
+    def __init__(self, events):
+        self.events = events
+
+    def wait(self):
+        import torch
+        cur = torch.cuda.current_stream()
+        for ev in self.events:
+            cur.wait_event(ev)          # stream-ordered, the host does not block
+        return True
+
+
 class _RankDist:
     def __init__(self, hub, rank):
         self.hub, self.rank = hub, rank
+        self._comm = None
+
+    def _comm_stream(self):
+        import torch
+        if self._comm is None:
+            self._comm = torch.cuda.Stream()
+        return self._comm
+
+    def _collective(self, payload, body, async_op):
+        import torch
+        hub = self.hub
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+        hub.slots[self.rank] = (payload, ready)
+        hub.barrier.wait()
+        comm = self._comm_stream()
+        with torch.cuda.stream(comm):
+            for src in range(hub.world):
+                comm.wait_event(hub.slots[src][1])
+            body([hub.slots[src][0] for src in range(hub.world)])
+            done = torch.cuda.Event()
+            done.record(comm)
+        hub.done[self.rank] = done
+        hub.barrier.wait()
+        # a rank's part of the collective is over when everybody has pulled its data, too
+        work = _Work(list(hub.done))
+        hub.barrier.wait()              # slots may be reused by the next call
+        if async_op:
+            return work
+        work.wait()
+        return None
 
     def all_gather_into_tensor(self, out, t):
         import torch
-        torch.cuda.synchronize()
-        self.hub.slots[self.rank] = t
-        self.hub.barrier.wait()
-        out.copy_(torch.cat([self.hub.slots[i] for i in range(self.hub.world)]))
-        torch.cuda.synchronize()
-        self.hub.barrier.wait()
+        self._collective(t, lambda parts: out.copy_(torch.cat(parts)), False)
 
     def all_to_all_single(self, out, inp, out_splits, in_splits, async_op=False):
-        import torch
-        torch.cuda.synchronize()
-        self.hub.slots[self.rank] = (inp, in_splits)
-        self.hub.barrier.wait()
-        pos = 0
-        for src in range(self.hub.world):
-            s_inp, s_splits = self.hub.slots[src]
-            off, cnt = sum(s_splits[:self.rank]), s_splits[self.rank]
-            assert cnt == out_splits[src]
-            out[pos:pos + cnt].copy_(s_inp[off:off + cnt])
-            pos += cnt
-        torch.cuda.synchronize()
-        self.hub.barrier.wait()
+        def body(parts):
+            pos = 0
+            for src, (s_inp, s_splits) in enumerate(parts):
+                off, cnt = sum(s_splits[:self.rank]), s_splits[self.rank]
+                assert cnt == out_splits[src]
+                out[pos:pos + cnt].copy_(s_inp[off:off + cnt])
+                pos += cnt
+        return self._collective((inp, in_splits), body, async_op)
 
 
 def _make_full(kind, dtype, n, oracle):
@@ -94,11 +135,13 @@ def test_ranks_on_one_gpu(rsx, oracle, dtype, kind, with_payload, world, strateg
                     spay = torch.empty_like(pay)
                     rpay = torch.empty(n * world, dtype=torch.int32, device="cuda")
                 with rsx.Engine(dtype, n * world, payload=with_payload) as eng:
-                    eng.set_stream(stream.cuda_stream)
+                    if rank % 2 == 0:
+                        eng.set_stream(stream.cuda_stream)      # odd ranks leave it to the sorter, which must bind the engine to torch's current stream itself
                     sorter = ShardedSorter(eng, rank, world, np.dtype(dtype).itemsize * 8, hub.view(rank), strategy=strategy)
                     obuf = torch.empty_like(recv)
                     opay = torch.empty_like(rpay) if with_payload else None
                     n_local = sorter.sort(keys, staging, recv, pay, spay, rpay, obuf, opay)
+                    assert eng.get_stream() == stream.cuda_stream
                     if sorter.result_in_out:
                         torch.cuda.synchronize()
                         out = (obuf[:n_local].cpu().numpy().view(np.dtype(dtype)), opay[:n_local].cpu().numpy().view(np.uint32) if with_payload else None)
@@ -228,23 +271,46 @@ def test_world_size_one_is_plain_sort(rsx, oracle):
         assert np.array_equal(eng.download(), np.sort(keys_np))
 
 
-def test_bench_through_rccl_single_rank():
-    """bench.py launched by torch.distributed.run with ONE rank and RSX_FORCE_EXCHANGE=1: the
-    whole multi-GPU step (rsx_partition, all_gather of bucket counts, all_to_all_single with
-    split sizes, local sort) runs through the real nccl/RCCL backend, talking to itself."""
+def _bench(args, env_extra=None):
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, RSX_FORCE_EXCHANGE="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--log2-keys", "22"]
-    proc = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    env = dict(os.environ, **(env_extra or {}))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    proc = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-3000:]
-    line = json.loads([l for l in proc.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["config"]["verified"] is True and line["n_gpus"] == 1
-    assert "all_to_all" in line["config"]["parallelism"] and line["value"] > 0
+    return json.loads([l for l in proc.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_through_rccl_single_rank():
+    """`python bench.py --gpus 1` with RSX_FORCE_EXCHANGE=1: the whole multi-GPU step (wave-major
+    partition, all_gather of bucket counts and buffer capacities, asynchronous all_to_all_single
+    with split sizes, partial local sorts) and the verification gather run through the real
+    nccl/RCCL backend, one rank talking to itself."""
+    line = _bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--log2-keys", "22", "--cpu-sample-log2", "20"], {"RSX_FORCE_EXCHANGE": "1"})
+    assert line["n_gpus"] == 1 and line["value"] > 0 and "rehearsal" not in line
+    assert line["config"]["verified"].startswith("bit-exact vs a host sort of all 4194304 keys")
+    assert "all_to_all" in line["config"]["parallelism"] and "waves" in line["config"]["parallelism"]
+    assert line["cpu_baseline"]["value"] > 0 and line["roofline"]["frac"] > 0
+    assert {"count+plan", "scatter", "wait", "local_sort"} <= set(line["sharded_phases_ms"])
+
+
+@pytest.mark.parametrize("strategy,dtype,payload", [("top", "uint32", False), ("split", "int64", True), ("range", "uint64", False)])
+def test_bench_through_rccl_other_exchange_paths(strategy, dtype, payload):
+    line = _bench(["--gpus", "1", "--steps", "1", "--warmup", "1", "--log2-keys", "20", "--dtype", dtype, "--no-cpu-baseline"] + (["--payload"] if payload else []),
+                  {"RSX_FORCE_EXCHANGE": "1", "RSX_STRATEGY": strategy})
+    assert strategy in line["config"]["parallelism"] and line["config"]["verified"].startswith("bit-exact")
+
+
+def test_bench_default_line_is_bit_exact_vs_the_cpu_baseline():
+    """The N=1 line at a reduced size: the array the cpu_baseline leg sorted with RadixSortCPU is compared
+    with the GPU output, and the line says so."""
+    line = _bench(["--steps", "3", "--warmup", "1", "--log2-keys", "22", "--cpu-sample-log2", "22"])
+    assert line["config"]["verified"].startswith("bit-exact vs RadixSortCPU") and "4194304 keys" in line["config"]["verified"]
+    assert line["scaling"] == "weak" and line["config"]["workload"].startswith("2^22 uint32 Random")
 
 
 @pytest.mark.parametrize("dt", ["uint32", "int32", "uint64", "int64"])

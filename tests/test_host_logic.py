@@ -4,6 +4,7 @@ vectors produced by the reference's own Dataset.h."""
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -67,3 +68,44 @@ def test_harness_refuses_without_gpu():
     exe = os.path.join(HOST, "bin", "rsx_tests")
     proc = subprocess.run([exe, "--num-elements", "2048"], capture_output=True, text=True, timeout=120)
     assert proc.returncode == 2 and "no CPU fallback" in proc.stderr
+
+
+def _run_bench(args, env_extra=None, timeout=600):
+    import json
+    import subprocess
+    env = dict(os.environ, **(env_extra or {}))
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    return proc, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_launches_its_own_ranks_rehearsal():
+    """`python bench.py --gpus 2` from a plain shell: the parent spawns two ranks as CHILD processes
+    (no GPU call of its own), they run the complete N>1 rank logic on the CPU test double under gloo,
+    and rank 0's line comes back through the parent with n_gpus = 2, cpu_baseline and roofline present."""
+    proc, line = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--total-log2-keys", "15", "--cpu-sample-log2", "12"],
+                            {"RSX_BENCH_REHEARSAL": "1"})
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-3000:]
+    assert line["rehearsal"] is True and line["value"] is None and line["metric"].startswith("REHEARSAL")
+    assert line["n_gpus"] == 2 and line["config"]["total_keys"] == 1 << 15 and line["config"]["keys_per_gpu"] == 1 << 14
+    assert line["scaling"] == "strong" and "sharded 2x" in line["config"]["workload"]
+    assert line["config"]["verified"].startswith("bit-exact vs a host sort of all 32768 keys")
+    assert "waves" in line["config"]["parallelism"]
+    assert line["cpu_baseline"]["cores"] == 1 and line["cpu_baseline"]["value"] > 0
+    assert line["roofline"]["bound"] == "hbm" and "sharded_phases_ms" in line
+
+
+def test_bench_rehearsal_weak_scaling_and_payload():
+    proc, line = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--log2-keys", "13", "--dtype", "int64", "--payload", "--no-cpu-baseline"],
+                            {"RSX_BENCH_REHEARSAL": "1"})
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-3000:]
+    assert line["scaling"] == "weak" and line["config"]["keys_per_gpu"] == 1 << 13 and line["n_gpus"] == 2
+    assert "cpu_baseline" not in line
+
+
+def test_bench_launcher_propagates_a_failing_rank():
+    """A rank that dies must make `python bench.py --gpus N` exit non-zero and print no result line."""
+    proc, line = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--total-log2-keys", "0"], {"RSX_BENCH_REHEARSAL": "1"}, timeout=300)
+    assert proc.returncode != 0 and line is None            # 2^0 keys do not divide over two ranks
