@@ -302,7 +302,9 @@ def test_bench_through_rccl_single_rank():
 def test_bench_through_rccl_other_exchange_paths(strategy, dtype, payload):
     line = _bench(["--gpus", "1", "--steps", "1", "--warmup", "1", "--log2-keys", "20", "--dtype", dtype, "--no-cpu-baseline"] + (["--payload"] if payload else []),
                   {"RSX_FORCE_EXCHANGE": "1", "RSX_STRATEGY": strategy})
-    assert strategy in line["config"]["parallelism"] and line["config"]["verified"].startswith("bit-exact")
+    # one rank has no splitters to choose: the splitter path degenerates to its "all on one rank" shortcut
+    path = {"top": "top", "split": "equal", "range": "range"}[strategy]
+    assert f"[{path}]" in line["config"]["parallelism"] and line["config"]["verified"].startswith("bit-exact")
 
 
 def test_bench_default_line_is_bit_exact_vs_the_cpu_baseline():
