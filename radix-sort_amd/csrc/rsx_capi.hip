@@ -119,6 +119,10 @@ struct rsx_engine {
     int paste_scan = 1;                         // rsx_sort: scan #2 + paste in one launch (env RSX_PASTE_SCAN)
     uint32_t* temp = nullptr;                   // grand total of scan #2
     uint32_t* counts_next = nullptr;            // look-ahead histogram of the next pass, [tile][digit]
+#ifdef RSX_STAMPS
+    unsigned long long* stamps = nullptr;       // diagnostic build: 16 phase stamps per tile of ONE chosen launch
+    int stamp_pass = -1;                        // env RSX_STAMP_PASS: the pass whose reorder launch writes them
+#endif
     uint32_t* ref_table = nullptr;              // diagnostics in the reference's [digit][group][item] geometry
     uint32_t* ref_globsum = nullptr;
     const void* counted_keys = nullptr;         // rsx_partition_count left a raw table for exactly this input
@@ -348,7 +352,12 @@ int launch_reorder_t(rsx_engine* e, const void* in, void* out, const uint32_t* p
                        L::BYTES, e->stream, static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->table, count,
                        g.ntiles, g.tiles_per_xcd, e->xcd_remap | ((e->reverse_odd && ((shift / RSX_RADIX_BITS) & 1)) ? 2 : 0), shift, flip_mask<Key>(e), mask,
                        e->counts_next, next_shift,
-                       fold_paste ? static_cast<const uint32_t*>(e->globsum) : static_cast<const uint32_t*>(nullptr), lo, mul, split_set<Key>(e, nsplit));
+#ifdef RSX_STAMPS
+                       (shift == e->stamp_pass * RSX_RADIX_BITS) ? reinterpret_cast<const uint32_t*>(e->stamps) : static_cast<const uint32_t*>(nullptr),
+#else
+                       fold_paste ? static_cast<const uint32_t*>(e->globsum) : static_cast<const uint32_t*>(nullptr),
+#endif
+                       lo, mul, split_set<Key>(e, nsplit));
     RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
     return RSX_OK;
 }
@@ -679,6 +688,12 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
         return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(histograms)", err);
     if ((err = hipMalloc(reinterpret_cast<void**>(&e->counts_next), table_alloc)) != hipSuccess)
         return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(look-ahead counts)", err);
+#ifdef RSX_STAMPS
+    if ((err = hipMalloc(reinterpret_cast<void**>(&e->stamps), e->ntiles(capacity) * 16 * 8)) != hipSuccess)
+        return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(stamps)", err);
+    if (const char* env = std::getenv("RSX_STAMP_PASS")) e->stamp_pass = std::atoi(env);
+    e->fold_paste = 0;
+#endif
     if ((err = hipMalloc(reinterpret_cast<void**>(&e->globsum), rsx::kMaxScanBlocks * 4)) != hipSuccess)
         return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(globsum)", err);
     if ((err = hipMalloc(reinterpret_cast<void**>(&e->globsum2), rsx::kMaxScanBlocks * 4)) != hipSuccess)
@@ -1360,6 +1375,17 @@ int rsx_copy_result(rsx_engine* e, void* d_keys_out, uint32_t* d_payload_out)
     }
     return RSX_OK;
 }
+
+#ifdef RSX_STAMPS
+// diagnostic build only: the 16 stamps of the first `tiles` tiles of the chosen launch
+int rsx_debug_stamps(rsx_engine* e, unsigned long long* host_out, uint64_t tiles)
+{
+    if (!e || !host_out) return RSX_CALCULATION_FAILED;
+    RSX_TRY(hipStreamSynchronize(e->stream), RSX_CALCULATION_FAILED);
+    RSX_TRY(hipMemcpy(host_out, e->stamps, std::min<uint64_t>(tiles, e->ntiles(e->capacity)) * 16 * 8, hipMemcpyDeviceToHost), RSX_CALCULATION_FAILED);
+    return RSX_OK;
+}
+#endif
 
 int rsx_timings(rsx_engine* e, rsx_runtimes* out, int reset)
 {

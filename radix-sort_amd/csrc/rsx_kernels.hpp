@@ -32,18 +32,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-// 1 (default): every lane loads its own 16 consecutive keys straight from HBM (64 contiguous
-// bytes per lane, 16-byte loads).  0: 16 B/lane coalesced loads + a transposition through LDS.
-// Measured on MI355X (2^28 uint32): same speed for the plain reorder, 7 % faster for the fused
-// look-ahead reorder (less LDS traffic, one barrier fewer) — see profiles/r01_tuning_log.md.
-#ifndef RSX_DIRECT_LOAD
-#define RSX_DIRECT_LOAD 1
-#endif
-// 1: digits are extracted with v_bfe_u32 (one instruction) instead of shift + and
-#ifndef RSX_DIGIT_BFE
-#define RSX_DIGIT_BFE 1
-#endif
-
 namespace rsx {
 
 constexpr int kRadixBits = 4;
@@ -78,21 +66,6 @@ __device__ __forceinline__ uint32_t digit_of(Key key, int shift, Key flip, uint3
     // `key + OFFSET` with OFFSET = -numeric_limits<T>::min() (RadixSortGPU.cpp:436-440,
     // RadixSort.cl:51) is exactly an XOR of the sign bit.
     return static_cast<uint32_t>((key ^ flip) >> shift) & mask;
-}
-
-// The 4-bit digit of the sort passes (mask 15 known at compile time).  32-bit keys: one v_bfe_u32 with
-// a literal width instead of shift + and.  (With the width in a register the instruction needs a
-// second VGPR operand — the constant bus takes one scalar — and the fused kernel, which sits exactly
-// at its 96-VGPR budget, spills: measured 3 % slower.  64-bit keys keep the plain route.)
-template <typename Key>
-__device__ __forceinline__ uint32_t digit4_of(Key key, int shift, Key flip)
-{
-#if RSX_DIGIT_BFE
-    if constexpr (sizeof(Key) == 4) {
-        return __builtin_amdgcn_ubfe(static_cast<uint32_t>(key ^ flip), static_cast<uint32_t>(shift), 4u);
-    }
-#endif
-    return static_cast<uint32_t>((key ^ flip) >> shift) & static_cast<uint32_t>(kRadix - 1);
 }
 
 // Bucket of the multi-GPU partition pass: x = (key ^ sign) - lo, 16 equal-width buckets over the
@@ -596,20 +569,23 @@ __global__ __launch_bounds__(kSmallScanThreads) void scan_small_kernel(uint32_t*
 // reorder: the stable scatter (the graded pass)
 // ---------------------------------------------------------------------------
 // LDS plan of one workgroup (dwords):
-//   xbuf  : first the striped->blocked transposition image (one row of KPT keys + 16 B
-//           pad per thread: ds_read_b128 of a row is bank-conflict-free), later the
-//           tile in locally sorted order (one pad element every 2^PADSH so that the
+//   xbuf  : the tile in locally sorted order (one pad element every 2^PADSH so that the
 //           stride-KPT writes of a single-digit tile do not pile on two banks)
 //   cnt   : 8 x THREADS packed counters, word [d&7][thread] holds digit d in its low
 //           (d<8) or high (d>=8) 16 bits
 //   wtot  : wave totals of the raking scan
-//   gbase : per digit, (global slot of the tile's first key of that digit) - (its local slot)
-// One key's contribution to the look-ahead counters.  All 64 lanes call this together.
-// If the whole wave hits one counter (single-digit data: Zeros, Range) one lane adds 64
-// instead of 64 lanes serialising on one LDS address.
+//   runs  : per digit, {(global slot of the tile's first key of that digit) - (its local slot), look-ahead base}
+//   la    : look-ahead counters [digit][segment 0/1][next digit] + one dummy
+//
+// Instruction count matters as much as bytes here: measured on MI355X the fused kernel's time follows
+// the shader clock (0.42 ms at 2.4 GHz, 0.50 ms at 1.9 GHz — the clock the power controller drops to for a
+// few milliseconds when a sort starts on an idle GPU, which is every sort in the reference's upload ->
+// sort -> download order), while the plain kernel stays at its HBM time.  Hence the hand-placed address
+// arithmetic below: every per-key step is written so that it compiles to the fewest VALU instructions
+// (profiles/r02_tuning_log.md has the before/after ISA counts).
 struct alignas(8) RunBase {
     uint32_t gbase;      // (global slot of the tile's first key of this digit) - (its tile-local slot)
-    uint32_t run_tile;   // output tile that global slot falls in
+    uint32_t la_base;    // (digit << 5) - (output tile of that global slot << 4): la index of a key = la_base + (tile of ITS slot << 4) + next digit
 };
 
 // Look-ahead histogram: one key's contribution to la[(digit, segment)][next digit].
@@ -631,25 +607,66 @@ __device__ __forceinline__ void lookahead_count(uint32_t* la, uint32_t idx)
     }
 }
 
+// (a + b) << SH in ONE instruction.  hipcc lowers `(slot + (slot >> 5)) * 4` to shift, shift, and, add3 (it
+// distributes the multiplication); the staging address of every key is exactly this expression.
+template <int SH>
+__device__ __forceinline__ uint32_t add_lshl(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_add_lshl_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "n"(SH));
+    return r;
+}
+
+// A store to the workgroup's LDS at a BYTE OFFSET from its start.  The kernels below carve everything out of one
+// `extern __shared__` array and declare no static LDS, so that array starts at LDS address 0 — but hipcc
+// only learns this after instruction selection and otherwise spends one `v_add_u32 addr, 0, addr` per
+// computed address.  reorder_kernel checks the assumption once per workgroup (lds_base_is_zero).
+template <typename T>
+__device__ __forceinline__ void lds_store_at(uint32_t byte_offset, T value)
+{
+    *reinterpret_cast<__attribute__((address_space(3))) T*>(static_cast<uintptr_t>(byte_offset)) = value;
+}
+__device__ __forceinline__ bool lds_base_is_zero(const void* dynamic_lds)
+{
+    return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) const char*)dynamic_lds)) == 0u;
+}
+
+// The 32-bit word of a key that holds the bit field starting at `shift` (fields never straddle the two
+// halves of a 64-bit key: the sort's digits are 4-bit aligned); `hi` is wave-uniform.
+__device__ __forceinline__ uint32_t field_word(uint32_t key, bool) { return key; }
+__device__ __forceinline__ uint32_t field_word(uint64_t key, bool hi) { return hi ? static_cast<uint32_t>(key >> 32) : static_cast<uint32_t>(key); }
+
+// Diagnostic build only (-DRSX_STAMPS, tools/stamp_probe.py): wave 0 of every workgroup writes the shader-cycle
+// counter at the phase boundaries of reorder_kernel into a buffer of its own (16 words per tile) that no other
+// code reads; the pointer travels in the otherwise unused `globsum` argument.  The product build has no stamp.
+#ifdef RSX_STAMPS
+#define RSX_STAMP(k)                                                                                      \
+    do {                                                                                                  \
+        if (stamp_buf && tid == 0) {                                                                      \
+            unsigned long long t_;                                                                        \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
+            stamp_buf[static_cast<uint64_t>(tile) * 16 + (k)] = t_;                                       \
+        }                                                                                                 \
+    } while (0)
+#else
+#define RSX_STAMP(k) do { } while (0)
+#endif
+
 template <typename Key, int THREADS, int KPT>
 struct ReorderLayout {
     static constexpr int TILE = THREADS * KPT;
     static constexpr int KD = sizeof(Key) / 4;
-    static constexpr int ROW_DW = KPT * KD + 4;
     static constexpr int PADSH = (KD == 1) ? 5 : 4;
     static constexpr int XELEMS = TILE + (TILE >> PADSH);
-#if RSX_DIRECT_LOAD
-    static constexpr int XBUF_DW = XELEMS * KD;             // no transposition image
-#else
-    static constexpr int XBUF_DW = (THREADS * ROW_DW > XELEMS * KD) ? THREADS * ROW_DW : XELEMS * KD;
-#endif
+    static constexpr int XBUF_DW = XELEMS * KD;
     static constexpr int CNT_DW = 8 * THREADS;
     static constexpr int WTOT_DW = 16;
-    static constexpr int GBASE_DW = 2 * kRadix;             // per digit {gbase, first output tile of the run}: one ds_read_b64
+    static constexpr int GBASE_DW = 2 * kRadix;             // per digit {gbase, la_base}: one ds_read_b64
     static constexpr int LA_DW = kRadix * 2 * kRadix + 16;  // look-ahead counters [digit][segment 0/1][next digit] + dummy
     static constexpr int TOTAL_DW = XBUF_DW + CNT_DW + WTOT_DW + GBASE_DW + LA_DW;
     static constexpr int TILE_SHIFT = __builtin_ctz(TILE);
     static_assert((TILE & (TILE - 1)) == 0, "tile size must be a power of two (slot -> output tile by shift)");
+    static_assert(THREADS % (1 << PADSH) == 0, "the padded index of slot r*THREADS+t must split into a per-thread base and a constant");
     static constexpr size_t BYTES = static_cast<size_t>(TOTAL_DW) * 4;
     // Workgroups one CU can hold by LDS (160 KiB) -> waves per SIMD the register allocator must
     // leave room for (second __launch_bounds__ argument = waves per SIMD, not blocks per CU).
@@ -675,6 +692,10 @@ constexpr int reorder_min_waves()
 // HBM.  A run (one digit of one source tile) covers at most two output tiles, so the
 // counts are first gathered in LDS as [digit][segment 0/1][next digit] and then flushed
 // with one global atomic per non-zero counter (16 consecutive lanes -> one 64-B segment).
+// The LOOKAHEAD variant serves rsx_sort's passes only: its digit is exactly the 4-bit field at `shift`
+// (mask 15) and the next digit the field at `next_shift`.  It works on RAW fields (no sign flip per
+// key): the sign bit only ever toggles the top bit of the top digit, which is folded into where the
+// counters, the run bases and the flushed counts are PLACED (flip_cur / flip_next below).
 template <typename Key, int THREADS, int KPT, bool PAYLOAD, bool LOOKAHEAD, bool RANGED = false>
 __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYLOAD>())) void reorder_kernel(const Key* __restrict__ in, Key* __restrict__ out,
                                                            const uint32_t* __restrict__ pin, uint32_t* __restrict__ pout,
@@ -686,23 +707,11 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
 {
     using L = ReorderLayout<Key, THREADS, KPT>;
     static_assert(!(RANGED && LOOKAHEAD), "the ranged bucket function is for the one-pass partition only");
-    auto dig = [=](Key key) -> uint32_t {
-        if constexpr (RANGED) {
-            if (split.n) {
-                return splitter_bucket(static_cast<Key>(key ^ flip), split);
-            }
-            const uint32_t b = ranged_bucket(static_cast<Key>((key ^ flip) - lo), shift, mul, mask);
-            return split.rot ? wave_major(b, split.rot) : b;
-        } else if constexpr (LOOKAHEAD) {
-            return digit4_of(key, shift, flip);          // only rsx_sort's passes run the fused variant: mask is 15
-        } else {
-            return digit_of(key, shift, flip, mask);
-        }
-    };
+    constexpr bool RAW = LOOKAHEAD;                 // digits are raw 4-bit fields; the sign flip lives in the placement
     constexpr int TILE = L::TILE;
     constexpr int VEC = KeyVec<Key>::N;
     constexpr int NV = KPT / VEC;
-    [[maybe_unused]] constexpr int KD = L::KD;      // dwords per key (only the LDS-transposition variant uses it)
+    constexpr uint32_t CNT_ROW_BYTES = THREADS * 4;           // one [digit&7] row of packed counters
 
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* xbuf = smem;
@@ -716,6 +725,9 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
     if (slot_tile >= ntiles) {
         return;
     }
+    if (!lds_base_is_zero(smem)) {
+        __builtin_trap();           // lds_store_at addresses the staging image from LDS address 0
+    }
     // bit 1 of `remap`: walk the tiles from the back (experiment: start with what the previous pass wrote last)
     const uint32_t tile = (remap & 2) ? ntiles - 1 - slot_tile : slot_tile;
     const uint64_t base = static_cast<uint64_t>(tile) * TILE;
@@ -725,6 +737,40 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
     // Slots past `valid` hold a key whose digit is 15 in every pass; being last in index
     // order as well they land in local slots [valid, TILE) and are never stored.
     const Key pad_key = static_cast<Key>(~flip);
+#ifdef RSX_STAMPS
+    unsigned long long* stamp_buf = reinterpret_cast<unsigned long long*>(const_cast<uint32_t*>(globsum));
+    globsum = nullptr;
+    if (stamp_buf && tid == 0) {
+        unsigned long long rt_;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_)::"memory");
+        stamp_buf[static_cast<uint64_t>(tile) * 16 + 14] = rt_;
+    }
+    RSX_STAMP(0);
+#endif
+
+    // RAW placement constants (wave-uniform, scalar registers): which 32-bit word of the key holds the
+    // digit, the field position inside it, and whether the sign bit is the digit's top bit.
+    const bool hi_cur = sizeof(Key) == 8 && shift >= 32;
+    const bool hi_next = sizeof(Key) == 8 && next_shift >= 32;
+    const uint32_t sh = static_cast<uint32_t>(shift) & 31u;
+    const uint32_t nsh = static_cast<uint32_t>(next_shift) & 31u;
+    const uint32_t flip_cur = RAW ? static_cast<uint32_t>((flip >> shift) & Key{kRadix - 1}) : 0u;        // 0 or 8 (non-RAW digits are true digits already)
+    const uint32_t flip_next = LOOKAHEAD ? static_cast<uint32_t>((flip >> next_shift) & Key{kRadix - 1}) : 0u;
+
+    // digit of a key as phases 2, 4 and 5 index with it: RAW -> the raw field; otherwise the true digit / bucket
+    auto dig = [=](Key key) -> uint32_t {
+        if constexpr (RANGED) {
+            if (split.n) {
+                return splitter_bucket(static_cast<Key>(key ^ flip), split);
+            }
+            const uint32_t b = ranged_bucket(static_cast<Key>((key ^ flip) - lo), shift, mul, mask);
+            return split.rot ? wave_major(b, split.rot) : b;
+        } else if constexpr (RAW) {
+            return __builtin_amdgcn_ubfe(field_word(key, hi_cur), sh, 4u);
+        } else {
+            return digit_of(key, shift, flip, mask);
+        }
+    };
 
     // The 8 raking threads whose first scan word belongs to thread 0 (digits hl and hl+8)
     // fetch table[digit][tile] for those two digits now, so the latency hides under the key loads.
@@ -746,11 +792,8 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
         }
     }
 
-    // ---- 1. coalesced load (striped, 16 B per lane) -> LDS rows (blocked) ----------
+    // ---- 1. every lane fetches its own KPT consecutive keys (64 contiguous bytes, 16-byte loads) ----
     Key k[KPT];
-#if RSX_DIRECT_LOAD
-    // Variant: every lane fetches its own 16 consecutive keys (64 contiguous bytes) with
-    // 16-byte loads and no LDS transposition; lines are shared by 2 lanes per instruction.
     if (full) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
@@ -767,33 +810,6 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
             k[i] = li < valid ? in[base + li] : pad_key;
         }
     }
-#else
-    {
-        KeyVec<Key> v[NV];
-        if (full) {
-#pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                v[j] = *reinterpret_cast<const KeyVec<Key>*>(in + base + static_cast<uint32_t>(j) * THREADS * VEC + tid * VEC);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < NV; ++j) {
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    const uint32_t li = static_cast<uint32_t>(j) * THREADS * VEC + tid * VEC + e;
-                    v[j].k[e] = li < valid ? in[base + li] : pad_key;
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            const uint32_t li = static_cast<uint32_t>(j) * THREADS * VEC + tid * VEC;
-            const uint32_t owner = li / KPT;
-            const uint32_t within = li % KPT;
-            *reinterpret_cast<KeyVec<Key>*>(xbuf + owner * L::ROW_DW + within * KD) = v[j];
-        }
-    }
-#endif
     // payload of the thread's blocked keys straight from HBM (64 B contiguous per lane)
     uint32_t pl[PAYLOAD ? KPT : 1];
     if constexpr (PAYLOAD) {
@@ -814,22 +830,8 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
             }
         }
     }
-#if !RSX_DIRECT_LOAD
-    __syncthreads();
-#endif
 
     // ---- 2. each thread = one virtual processor: KPT consecutive keys, private counters
-#if !RSX_DIRECT_LOAD
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        const KeyVec<Key> v = *reinterpret_cast<const KeyVec<Key>*>(xbuf + tid * L::ROW_DW + j * VEC * KD);
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            k[j * VEC + e] = v.k[e];
-        }
-    }
-#endif
-    u16_alias* cnt16 = reinterpret_cast<u16_alias*>(cnt);
     u32_alias* cnt32 = reinterpret_cast<u32_alias*>(cnt);
 #pragma unroll
     for (int l = 0; l < 8; ++l) {
@@ -840,9 +842,30 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
             la[c] = 0;
         }
     }
+#ifdef RSX_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RSX_STAMP(1);
+#endif
     uint32_t slot[KPT];      // first: rank among the thread's own equal-digit keys; later: tile-local slot
-    // 16-bit counter of (digit d, this thread): word [d&7][tid], half d>>3
-    auto counter_index = [tid](uint32_t d) { return (((d & 7u) * THREADS + tid) << 1) + (d >> 3); };
+    // Byte address (inside the counter area) of the 16-bit counter of (TRUE digit d, this thread):
+    // word [d&7][tid], half d>>3  ->  (d&7) * THREADS*4 + tid*4 + (d>>3)*2.
+    //   RAW:   two bit-field extracts and two multiply-adds per key; the sign flip of the top pass (true
+    //          d>>3 = raw d>>3 ^ 1) is a NEGATIVE half stride from a base 2 bytes up — no instruction per key.
+    //   other: the digit is computed once (it may be a 20-instruction bucket function) and split.
+    unsigned char* cbytes = reinterpret_cast<unsigned char*>(cnt);
+    const uint32_t cbase = tid * 4u + (flip_cur ? 2u : 0u);
+    const int half_stride = flip_cur ? -2 : 2;
+    auto counter_at = [&](Key key) -> u16_alias* {
+        if constexpr (RAW) {
+            const uint32_t w = field_word(key, hi_cur);
+            const uint32_t l3 = __builtin_amdgcn_ubfe(w, sh, 3u);
+            const int h = static_cast<int>(__builtin_amdgcn_ubfe(w, sh + 3u, 1u));
+            return reinterpret_cast<u16_alias*>(cbytes + (l3 * CNT_ROW_BYTES + cbase) + __mul24(h, half_stride));
+        } else {
+            const uint32_t d = dig(key);
+            return reinterpret_cast<u16_alias*>(cbytes + ((d & 7u) * CNT_ROW_BYTES + tid * 4u) + (d >> 3) * 2u);
+        }
+    };
     // RANGED: the bucket function costs tens of instructions per key, so it is evaluated once:
     // the thread's 16 buckets are kept as nibbles, and travel to step 5 as bytes next to the
     // staged keys (in the counter area, which is free by then)
@@ -854,6 +877,7 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
             return dig(k[i]);
         }
     };
+    u16_alias* cptr[KPT];
     if constexpr (RANGED) {
 #pragma unroll
         for (int w = 0; w < KPT / 8; ++w) {
@@ -866,12 +890,19 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
     }
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
-        const uint32_t ci = counter_index(bucket_at(i));
-        const uint32_t c = cnt16[ci];
+        if constexpr (RANGED) {
+            const uint32_t d = bucket_at(i);
+            cptr[i] = reinterpret_cast<u16_alias*>(cbytes + ((d & 7u) * CNT_ROW_BYTES + tid * 4u) + (d >> 3) * 2u);
+        } else {
+            cptr[i] = counter_at(k[i]);
+        }
+        const uint32_t c = *cptr[i];
         slot[i] = c;
-        cnt16[ci] = static_cast<uint16_t>(c + 1);
+        *cptr[i] = static_cast<uint16_t>(c + 1);
     }
+    RSX_STAMP(2);
     __syncthreads();
+    RSX_STAMP(3);
 
     // ---- 3. raking scan over the 8*THREADS packed words in [digit&7][thread] order ---
     {
@@ -884,10 +915,12 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
         // after ALL keys with digit < 8, i.e. after total.low
         run += total << 16;
         if (rake_head) {
-            // `run` is the scanned word of (digit hl | hl+8, thread 0): the tile-local slot of
-            // the tile's first key with that digit
-            runs[hl] = RunBase{first_lo - (run & 0xFFFFu), first_lo >> L::TILE_SHIFT};
-            runs[hl + 8] = RunBase{first_hi - (run >> 16), first_hi >> L::TILE_SHIFT};
+            // `run` is the scanned word of (true digit hl | hl+8, thread 0): the tile-local slot of the
+            // tile's first key with that digit.  Stored where phase 5 looks it up: at the RAW digit.
+            const uint32_t g_lo = first_lo - (run & 0xFFFFu), g_hi = first_hi - (run >> 16);
+            const uint32_t r_lo = hl ^ flip_cur, r_hi = (hl + 8u) ^ flip_cur;
+            runs[r_lo] = RunBase{g_lo, (r_lo << 5) - ((first_lo >> L::TILE_SHIFT) << 4)};
+            runs[r_hi] = RunBase{g_hi, (r_hi << 5) - ((first_hi >> L::TILE_SHIFT) << 4)};
         }
         uint32_t t;
         t = a.v[0]; a.v[0] = run; run += t;
@@ -902,6 +935,7 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
         *reinterpret_cast<U32x4*>(cnt + tid * 8 + 4) = b;
     }
     __syncthreads();
+    RSX_STAMP(4);
 
     // ---- 4. tile-local slot of every key; stage the tile in sorted order -------------
     // Written as "all reads, then all writes" on purpose: the compiler cannot prove that the
@@ -912,7 +946,7 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
         uint32_t first_of_digit[KPT];
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
-            first_of_digit[i] = cnt16[counter_index(bucket_at(i))];
+            first_of_digit[i] = *cptr[i];
         }
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
@@ -920,7 +954,8 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
         }
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
-            xk[slot[i] + (slot[i] >> L::PADSH)] = k[i];
+            // xk[slot + (slot >> PADSH)] = k  (xbuf is the first thing in the workgroup's LDS)
+            lds_store_at<Key>(add_lshl<(sizeof(Key) == 4 ? 2 : 3)>(slot[i], slot[i] >> L::PADSH), k[i]);
         }
         if constexpr (RANGED) {
             __syncthreads();                 // every thread has read its counters: reuse the area
@@ -932,16 +967,20 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
         }
     }
     __syncthreads();
+    RSX_STAMP(5);
 
     // ---- 5. leave as runs: consecutive lanes -> consecutive addresses inside a run ---
-    // Same batching: 16 key reads in flight, then 16 run-base reads, then 16 stores.
+    // Same batching: 16 key reads in flight, then 16 run-base reads, then 16 stores.  Slot
+    // i = r*THREADS + tid sits at padded index i + (i >> PADSH) = (tid + (tid >> PADSH)) + r*RSTRIDE: one
+    // per-thread base and compile-time offsets, no address arithmetic per key.
+    constexpr uint32_t RSTRIDE = THREADS + (THREADS >> L::PADSH);
+    const uint32_t rd_base = tid + (tid >> L::PADSH);
     Key okey[KPT];
     uint32_t g[KPT];
     uint32_t la_idx[LOOKAHEAD ? KPT : 1];
 #pragma unroll
     for (int r = 0; r < KPT; ++r) {
-        const uint32_t i = static_cast<uint32_t>(r) * THREADS + tid;
-        okey[r] = xk[i + (i >> L::PADSH)];
+        okey[r] = xk[rd_base + static_cast<uint32_t>(r) * RSTRIDE];
     }
     {
         RunBase rb[KPT];
@@ -955,14 +994,14 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
         }
 #pragma unroll
         for (int r = 0; r < KPT; ++r) {
-            const uint32_t i = static_cast<uint32_t>(r) * THREADS + tid;
-            g[r] = rb[r].gbase + i;
+            g[r] = rb[r].gbase + tid + static_cast<uint32_t>(r) * THREADS;
             if constexpr (LOOKAHEAD) {
-                la_idx[r] = (dig(okey[r]) << 5) + (((g[r] >> L::TILE_SHIFT) - rb[r].run_tile) << 4) +
-                            digit4_of(okey[r], next_shift, flip);
+                // counter [digit][segment][next digit]: la_base = (digit << 5) - (first output tile << 4)
+                la_idx[r] = rb[r].la_base + ((g[r] >> L::TILE_SHIFT) << 4) + __builtin_amdgcn_ubfe(field_word(okey[r], hi_next), nsh, 4u);
             }
         }
     }
+    RSX_STAMP(6);
     // keys leave first, then the look-ahead counts: both free their registers before the
     // payload takes its own trip through the staging image
     if (full) {
@@ -981,24 +1020,38 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
             }
         }
     }
+    RSX_STAMP(7);
     if constexpr (LOOKAHEAD) {
+        // Wave-uniform counters (constant or sorted data) must not become 64 lanes serialising on one LDS
+        // address, but testing every key for it costs a scalar branch and an LDS drain per key.  Round 0
+        // stands for the wave: where its 64 slots already disagree (any data with entropy in these two
+        // digits) the other rounds simply add; otherwise every round is tested.
+        const uint32_t first0 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(la_idx[0])));
+        if (__builtin_expect(__ballot(la_idx[0] != first0) != 0ull, 1)) {
 #pragma unroll
-        for (int r = 0; r < KPT; ++r) {
-            lookahead_count(la, la_idx[r]);
+            for (int r = 0; r < KPT; ++r) {
+                atomicAdd(&la[la_idx[r]], 1u);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < KPT; ++r) {
+                lookahead_count(la, la_idx[r]);
+            }
         }
     }
     if constexpr (PAYLOAD) {
         __syncthreads();      // every wave has read its keys: the image may be overwritten
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
-            xbuf[slot[i] + (slot[i] >> 5)] = pl[i];
+            lds_store_at<uint32_t>(add_lshl<2>(slot[i], slot[i] >> 5), pl[i]);
         }
         __syncthreads();
+        constexpr uint32_t PSTRIDE = THREADS + (THREADS >> 5);
+        const uint32_t pd_base = tid + (tid >> 5);
         uint32_t pay[KPT];
 #pragma unroll
         for (int r = 0; r < KPT; ++r) {
-            const uint32_t i = static_cast<uint32_t>(r) * THREADS + tid;
-            pay[r] = xbuf[i + (i >> 5)];
+            pay[r] = xbuf[pd_base + static_cast<uint32_t>(r) * PSTRIDE];
         }
 #pragma unroll
         for (int r = 0; r < KPT; ++r) {
@@ -1008,8 +1061,10 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
             }
         }
     }
+    RSX_STAMP(8);
     if constexpr (LOOKAHEAD) {
         __syncthreads();
+        RSX_STAMP(9);
         // an opaque copy of the thread id: otherwise the compiler shares `tid >> 5` address arithmetic with
         // the ranking phase, keeps it alive through the whole kernel and spills it at the 96-VGPR budget
         uint32_t first = tid;
@@ -1017,11 +1072,23 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
         for (uint32_t c = first; c < kLaDummy; c += THREADS) {
             const uint32_t v = la[c];
             if (v) {
-                const uint32_t d = c >> 5, seg = (c >> 4) & 1u, d2 = c & 15u;
-                atomicAdd(&next_counts[static_cast<uint64_t>(runs[d].run_tile + seg) * kRadix + d2], v);
+                // counter c = [raw digit d][segment][raw next digit]; the counts table is indexed by the TRUE next digit
+                const uint32_t d = c >> 5, seg = (c >> 4) & 1u, d2 = (c & 15u) ^ flip_next;
+                const uint32_t run_tile = ((d << 5) - runs[d].la_base) >> 4;
+                atomicAdd(&next_counts[static_cast<uint64_t>(run_tile + seg) * kRadix + d2], v);
             }
         }
     }
+#ifdef RSX_STAMPS
+    RSX_STAMP(10);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // all stores and atomics of wave 0 acknowledged
+    RSX_STAMP(11);
+    if (stamp_buf && tid == 0) {
+        unsigned long long rt_;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_)::"memory");
+        stamp_buf[static_cast<uint64_t>(tile) * 16 + 15] = rt_;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------
