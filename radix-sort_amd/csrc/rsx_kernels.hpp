@@ -754,7 +754,10 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
     const bool hi_next = sizeof(Key) == 8 && next_shift >= 32;
     const uint32_t sh = static_cast<uint32_t>(shift) & 31u;
     const uint32_t nsh = static_cast<uint32_t>(next_shift) & 31u;
-    const uint32_t flip_cur = RAW ? static_cast<uint32_t>((flip >> shift) & Key{kRadix - 1}) : 0u;        // 0 or 8 (non-RAW digits are true digits already)
+    // RAW passes never sort by the digit that holds the sign bit (the most significant pass of a sort is always
+    // its last one, which runs the plain variant), so a raw current digit IS the true digit; only the NEXT digit
+    // may be the sign digit, and that is settled where the counts are flushed (flip_next).
+    constexpr uint32_t flip_cur = 0u;
     const uint32_t flip_next = LOOKAHEAD ? static_cast<uint32_t>((flip >> next_shift) & Key{kRadix - 1}) : 0u;
 
     // digit of a key as phases 2, 4 and 5 index with it: RAW -> the raw field; otherwise the true digit / bucket
@@ -831,12 +834,15 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
         }
     }
 
-    // ---- 2. each thread = one virtual processor: KPT consecutive keys, private counters
+    // ---- 2. each thread = one virtual processor: KPT consecutive keys, private counters ----------
+    // The 16 digit counters of a thread live in ONE 64-bit register while it ranks its keys (nibble d = keys
+    // seen so far with digit d; at most KPT-1 = 15 before the last key, so a nibble never overflows) and reach
+    // LDS only once, as the 8 packed words of the raking scan.  Counting in LDS instead — read, add, write per
+    // key on a counter that the next key may hit again — is a chain of 16 dependent LDS round trips: measured
+    // with in-kernel stamps it was 5,100-5,800 of a tile's 17,000 cycles of residency, and the kernel's
+    // throughput is residency-bound (4.7 tiles per CU in flight).
+    static_assert(KPT <= 16, "nibble counters: a thread's count of one digit must fit 4 bits before its last key");
     u32_alias* cnt32 = reinterpret_cast<u32_alias*>(cnt);
-#pragma unroll
-    for (int l = 0; l < 8; ++l) {
-        cnt32[l * THREADS + tid] = 0;
-    }
     if constexpr (LOOKAHEAD) {
         for (uint32_t c = tid; c < static_cast<uint32_t>(L::LA_DW); c += THREADS) {
             la[c] = 0;
@@ -846,26 +852,6 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     RSX_STAMP(1);
 #endif
-    uint32_t slot[KPT];      // first: rank among the thread's own equal-digit keys; later: tile-local slot
-    // Byte address (inside the counter area) of the 16-bit counter of (TRUE digit d, this thread):
-    // word [d&7][tid], half d>>3  ->  (d&7) * THREADS*4 + tid*4 + (d>>3)*2.
-    //   RAW:   two bit-field extracts and two multiply-adds per key; the sign flip of the top pass (true
-    //          d>>3 = raw d>>3 ^ 1) is a NEGATIVE half stride from a base 2 bytes up — no instruction per key.
-    //   other: the digit is computed once (it may be a 20-instruction bucket function) and split.
-    unsigned char* cbytes = reinterpret_cast<unsigned char*>(cnt);
-    const uint32_t cbase = tid * 4u + (flip_cur ? 2u : 0u);
-    const int half_stride = flip_cur ? -2 : 2;
-    auto counter_at = [&](Key key) -> u16_alias* {
-        if constexpr (RAW) {
-            const uint32_t w = field_word(key, hi_cur);
-            const uint32_t l3 = __builtin_amdgcn_ubfe(w, sh, 3u);
-            const int h = static_cast<int>(__builtin_amdgcn_ubfe(w, sh + 3u, 1u));
-            return reinterpret_cast<u16_alias*>(cbytes + (l3 * CNT_ROW_BYTES + cbase) + __mul24(h, half_stride));
-        } else {
-            const uint32_t d = dig(key);
-            return reinterpret_cast<u16_alias*>(cbytes + ((d & 7u) * CNT_ROW_BYTES + tid * 4u) + (d >> 3) * 2u);
-        }
-    };
     // RANGED: the bucket function costs tens of instructions per key, so it is evaluated once:
     // the thread's 16 buckets are kept as nibbles, and travel to step 5 as bytes next to the
     // staged keys (in the counter area, which is free by then)
@@ -877,7 +863,6 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
             return dig(k[i]);
         }
     };
-    u16_alias* cptr[KPT];
     if constexpr (RANGED) {
 #pragma unroll
         for (int w = 0; w < KPT / 8; ++w) {
@@ -888,18 +873,43 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
             nib[i >> 3] |= dig(k[i]) << ((i & 7) * 4);
         }
     }
+    uint32_t slot[KPT];      // first: rank among the thread's own equal-digit keys; later: tile-local slot
+    {
+        uint64_t seen = 0;
 #pragma unroll
-    for (int i = 0; i < KPT; ++i) {
-        if constexpr (RANGED) {
-            const uint32_t d = bucket_at(i);
-            cptr[i] = reinterpret_cast<u16_alias*>(cbytes + ((d & 7u) * CNT_ROW_BYTES + tid * 4u) + (d >> 3) * 2u);
-        } else {
-            cptr[i] = counter_at(k[i]);
+        for (int i = 0; i < KPT; ++i) {
+            const uint32_t sh4 = bucket_at(i) << 2;
+            slot[i] = static_cast<uint32_t>(seen >> sh4) & 15u;
+            if (i + 1 < KPT) {
+                seen += 1ull << sh4;
+            }
         }
-        const uint32_t c = *cptr[i];
-        slot[i] = c;
-        *cptr[i] = static_cast<uint16_t>(c + 1);
+        const uint32_t seen_lo = static_cast<uint32_t>(seen), seen_hi = static_cast<uint32_t>(seen >> 32);
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+            // word [l][tid]: digit l in the low half, digit l+8 in the high half
+            cnt32[l * THREADS + tid] = __builtin_amdgcn_ubfe(seen_lo, 4u * l, 4u) | (__builtin_amdgcn_ubfe(seen_hi, 4u * l, 4u) << 16);
+        }
+        // the last key: one add without return on the thread's own word, behind the store above (LDS
+        // operations of a wave execute in order)
+        const uint32_t d_last = bucket_at(KPT - 1);
+        atomicAdd(reinterpret_cast<uint32_t*>(cnt) + (d_last & 7u) * THREADS + tid, 1u << ((d_last >> 3) * 16u));
     }
+    // Byte address (inside the counter area) of the 16-bit counter of (digit d, this thread):
+    // word [d&7][tid], half d>>3  ->  (d&7) * THREADS*4 + tid*4 + (d>>3)*2.  RAW: two bit-field extracts and
+    // two shift-adds per key (LOOKAHEAD passes never sort by the sign digit: raw digit = true digit).
+    unsigned char* cbytes = reinterpret_cast<unsigned char*>(cnt);
+    auto counter_at = [&](int i) -> u16_alias* {
+        if constexpr (RAW) {
+            const uint32_t w = field_word(k[i], hi_cur);
+            const uint32_t l3 = __builtin_amdgcn_ubfe(w, sh, 3u);
+            const uint32_t h = __builtin_amdgcn_ubfe(w, sh + 3u, 1u);
+            return reinterpret_cast<u16_alias*>(cbytes + (l3 * CNT_ROW_BYTES + tid * 4u) + h * 2u);
+        } else {
+            const uint32_t d = bucket_at(i);
+            return reinterpret_cast<u16_alias*>(cbytes + ((d & 7u) * CNT_ROW_BYTES + tid * 4u) + (d >> 3) * 2u);
+        }
+    };
     RSX_STAMP(2);
     __syncthreads();
     RSX_STAMP(3);
@@ -946,7 +956,7 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
         uint32_t first_of_digit[KPT];
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
-            first_of_digit[i] = *cptr[i];
+            first_of_digit[i] = *counter_at(i);
         }
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
