@@ -67,6 +67,9 @@ typedef enum rsx_option {
                                  boundary, not host launch cost, sets the 0.1 ms floor of a 33-kernel sort). */
     RSX_OPT_SMALL_SCAN = 7,   /* 1 (default): inside rsx_sort, tables of at most 1024 tiles (2^22 keys) are scanned and
                                  pasted by ONE workgroup in one launch instead of three; the step API is unaffected */
+    RSX_OPT_TILE_SORT = 8,    /* 1 (default): inside rsx_sort, inputs of at most one tile (4096 keys) are sorted by ONE workgroup in
+                                 ONE launch, every pass inside LDS; buffers, table and group sums end up as the pass chain
+                                 leaves them.  Not taken while RSX_OPT_PROFILE is 1 (per-launch timings of the steps). */
     RSX_OPT_LOOKAHEAD = 4     /* 1 (default): inside rsx_sort the reorder of pass p also counts pass p+1's digits per
                                  output tile, so only the first pass runs the histogram kernel; 0: every pass runs
                                  histogram -> scan -> paste -> reorder separately.  Results are identical. */

@@ -151,6 +151,7 @@ struct rsx_engine {
     int reverse_odd = 0;                        // odd passes walk the tiles backwards (env RSX_REVERSE_ODD; measured, see the tuning log)
     int lookahead = 1;          // rsx_sort builds pass p+1's histogram inside pass p's reorder
     int small_scan = 1;         // rsx_sort: one-workgroup scan+paste for tables of <= 1024 tiles (env RSX_SMALL_SCAN)
+    int tile_sort = 1;          // rsx_sort: inputs of at most one tile are sorted by ONE workgroup in ONE launch, all passes in LDS (env RSX_TILE_SORT)
     int fold_paste = 0;         // reorder adds globsum itself (no paste launch): measured 3 % slower, off; env RSX_FOLD_PASTE
     int scan_zeroes = 1;
     int first_pass = 0;
@@ -432,9 +433,61 @@ int key_range(rsx_engine* e, const void* d_keys, uint64_t n, uint64_t* lo, uint6
     return RSX_OK;
 }
 
+// Inputs of at most one tile: every pass inside LDS, one launch (rsx::tile_sort_kernel).  The buffers end up
+// exactly as the pass chain would leave them: the result where the chain's last pass would have written it,
+// the order before the last pass in the other ping-pong buffer, table / group sums / total of the last pass.
+template <typename Key, bool PAYLOAD>
+int launch_tile_sort_t(rsx_engine* e, const void* in, void* out, void* before_last, const uint32_t* pin, uint32_t* pout, uint32_t* pbefore_last, uint64_t count)
+{
+    using L = rsx::TileSortLayout<Key, kTileThreads, kKeysPerThread>;
+    Bracket b(e, PH_REORDER);
+    hipLaunchKernelGGL((rsx::tile_sort_kernel<Key, kTileThreads, kKeysPerThread, PAYLOAD>), dim3(1), dim3(kTileThreads), L::BYTES, e->stream,
+                       static_cast<const Key*>(in), static_cast<Key*>(out), static_cast<Key*>(before_last), pin, pout, pbefore_last,
+                       static_cast<uint32_t>(count), e->first_pass, e->last_pass, flip_mask<Key>(e), e->table, e->globsum, e->temp);
+    RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
+    return RSX_OK;
+}
+
+template <typename Key>
+int sort_tile_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext_perm, uint64_t count)
+{
+    const int npasses = e->last_pass - e->first_pass;
+    const void* in = ext_keys ? ext_keys : e->keys[e->cur];
+    const uint32_t* pin = e->has_payload ? (ext_keys ? ext_perm : e->perm[e->cur]) : nullptr;
+    const int first_dst = ext_keys ? e->cur : (e->cur ^ 1);
+    const int final_buf = first_dst ^ ((npasses - 1) & 1);            // where the chain's last pass writes
+    void* out = e->final_keys_out ? e->final_keys_out : e->keys[final_buf];
+    uint32_t* pout = e->has_payload ? (e->final_keys_out ? e->final_perm_out : e->perm[final_buf]) : nullptr;
+    void* before_last = npasses > 1 ? e->keys[final_buf ^ 1] : nullptr;
+    uint32_t* pbefore_last = (npasses > 1 && e->has_payload) ? e->perm[final_buf ^ 1] : nullptr;
+    // (with internal input and an odd pass count `before_last` is the input buffer itself: the one workgroup has
+    // read all of it into registers before anything is written)
+    Bracket whole(e, PH_TOTAL);
+    e->counted_keys = nullptr;
+    e->globsum_live = e->globsum;
+    const int rc = e->has_payload ? launch_tile_sort_t<Key, true>(e, in, out, before_last, pin, pout, pbefore_last, count)
+                                  : launch_tile_sort_t<Key, false>(e, in, out, before_last, nullptr, nullptr, nullptr, count);
+    if (rc != RSX_OK) return rc;
+    e->last_in = npasses > 1 ? before_last : in;
+    e->last_shift = (e->last_pass - 1) * RSX_RADIX_BITS;
+    e->result_external = e->final_keys_out != nullptr;
+    if (e->final_keys_out) {
+        e->result_keys = e->final_keys_out;
+        e->result_perm = e->has_payload ? e->final_perm_out : nullptr;
+    } else {
+        e->cur = final_buf;
+        e->result_keys = e->keys[e->cur];
+        e->result_perm = e->has_payload ? e->perm[e->cur] : nullptr;
+    }
+    return RSX_OK;
+}
+
 template <typename Key>
 int sort_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext_perm, uint64_t count)
 {
+    if (e->tile_sort && e->profile != 1 && count > 0 && count <= static_cast<uint64_t>(kTileKeys) && e->first_pass < e->last_pass) {
+        return sort_tile_enqueue<Key>(e, ext_keys, ext_perm, count);
+    }
     // Ping-pong.  With external input the first pass reads the caller's buffer (never
     // written) and the chain continues inside the engine's two buffers.
     const void* in = ext_keys ? ext_keys : e->keys[e->cur];
@@ -656,6 +709,7 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
     if (const char* env = std::getenv("RSX_LOOKAHEAD")) e->lookahead = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_GRAPH")) e->use_graph = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_SMALL_SCAN")) e->small_scan = std::atoi(env) != 0;
+    if (const char* env = std::getenv("RSX_TILE_SORT")) e->tile_sort = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_PASTE_SCAN")) e->paste_scan = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_FOLD_PASTE")) e->fold_paste = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_SCAN_ZEROES")) e->scan_zeroes = std::atoi(env) != 0;
@@ -717,6 +771,16 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
         return bail(RSX_INITIALIZATION_FAILED, "hipMemsetAsync(globsum)", err);
 
     int rc = RSX_OK;
+    {
+        auto allow_tile = [](const void* fn, size_t bytes) { return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)); };
+        using L32 = rsx::TileSortLayout<uint32_t, kTileThreads, kKeysPerThread>;
+        using L64 = rsx::TileSortLayout<uint64_t, kTileThreads, kKeysPerThread>;
+        if (allow_tile(reinterpret_cast<const void*>(&rsx::tile_sort_kernel<uint32_t, kTileThreads, kKeysPerThread, false>), L32::BYTES) != hipSuccess ||
+            allow_tile(reinterpret_cast<const void*>(&rsx::tile_sort_kernel<uint32_t, kTileThreads, kKeysPerThread, true>), L32::BYTES) != hipSuccess ||
+            allow_tile(reinterpret_cast<const void*>(&rsx::tile_sort_kernel<uint64_t, kTileThreads, kKeysPerThread, false>), L64::BYTES) != hipSuccess ||
+            allow_tile(reinterpret_cast<const void*>(&rsx::tile_sort_kernel<uint64_t, kTileThreads, kKeysPerThread, true>), L64::BYTES) != hipSuccess)
+            rc = fail(RSX_INITIALIZATION_FAILED, "hipFuncSetAttribute(tile_sort_kernel)");
+    }
     if (rc == RSX_OK) rc = allow_lds<uint32_t, false, false>();
     if (rc == RSX_OK) rc = allow_lds<uint32_t, true, false>();
     if (rc == RSX_OK) rc = allow_lds<uint64_t, false, false>();
@@ -804,6 +868,7 @@ int rsx_set_option(rsx_engine* e, int option, int64_t value)
     case RSX_OPT_REF_DIAGNOSTICS: e->ref_diag = value != 0; return RSX_OK;
     case RSX_OPT_GRAPH: e->use_graph = value != 0; return RSX_OK;
     case RSX_OPT_SMALL_SCAN: e->small_scan = value != 0; return RSX_OK;
+    case RSX_OPT_TILE_SORT: e->tile_sort = value != 0; return RSX_OK;
     case RSX_OPT_FIRST_PASS:
         if (value < 0 || value > e->passes()) return fail(RSX_CALCULATION_FAILED, "rsx_set_option: first pass out of range");
         e->first_pass = static_cast<int>(value);

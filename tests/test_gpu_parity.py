@@ -418,6 +418,81 @@ def test_config5_inputs_2pow26_bit_exact_vs_oracle(mod, oracle, kind):
     assert np.array_equal(_sort(mod, keys), oracle.radix_sort(keys))
 
 
+# --------------------------------------------------------------------------- one-workgroup sort of small inputs
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("n", [1, 2, 17, 1000, 1024, 4095, 4096])
+def test_tile_sort_equals_the_pass_chain(mod, oracle, dt, n):
+    """Inputs of at most one tile take ONE launch (every pass inside LDS).  Everything observable must equal
+    what the multi-launch chain leaves behind: keys, payload (stable argsort), the last pass's table, and —
+    for the reference-compatible host mirror — the reference-geometry diagnostics."""
+    rng = np.random.default_rng(n)
+    info = np.iinfo(dt)
+    keys = rng.integers(info.min, info.max, size=n, dtype=dt, endpoint=True)
+    keys[: n // 3] = keys[0]                                    # ties: the payload order matters
+    perm = np.arange(n, dtype=np.uint32)
+    seen = {}
+    for tile_sort in (1, 0):
+        with mod.Engine(dt, 4096, payload=True) as e:
+            e.set_option(mod.OPT_TILE_SORT, tile_sort)
+            e.upload(keys, perm)
+            e.sort()
+            k, p, table = e.download(want_perm=True, hist_cap=16)
+            seen[tile_sort] = (k, p, table)
+    assert np.array_equal(seen[1][0], np.sort(keys)) and np.array_equal(seen[1][1], np.argsort(keys, kind="stable").astype(np.uint32))
+    for a, b in zip(seen[1], seen[0]):
+        assert np.array_equal(a, b)
+    if n % 1024 == 0:
+        want_sorted, want_table, want_gs = oracle.emulate_reference_gpu(keys)
+        with mod.Engine(dt, n) as e:
+            e.set_option(mod.OPT_REF_DIAGNOSTICS, 1)
+            e.upload(keys)
+            e.sort()
+            got, table, gs = e.download(hist_cap=16384, globsum_cap=512)
+        assert np.array_equal(got, want_sorted) and np.array_equal(table, want_table) and np.array_equal(gs, want_gs)
+
+
+@pytest.mark.parametrize("dt", ["uint32", "int64"])
+def test_tile_sort_pass_ranges_and_external_buffers(mod, oracle, dt):
+    """The one-launch path behind rsx_sort_from / rsx_sort_from_to: external input left untouched, partial and
+    odd pass ranges, output into a caller buffer, and repeated internal sorts (ping-pong parity)."""
+    import torch
+    n = 3001
+    keys = oracle.dataset("SeededUniform", dt, n, seed=11)
+    signed = {"uint32": np.int32, "uint64": np.int64}.get(np.dtype(dt).name)
+    t = torch.from_numpy(keys.view(signed) if signed else keys).cuda()
+    pay = torch.arange(n, dtype=torch.int32, device="cuda")
+    bits = keys.dtype.itemsize * 8
+    u = keys.view(np.uint32 if bits == 32 else np.uint64)
+    if keys.dtype.kind == "i":
+        u = u ^ u.dtype.type(1 << (bits - 1))
+    for tile_sort in (1, 0):
+        with mod.Engine(dt, 4096, payload=True) as e:
+            e.set_stream(torch.cuda.current_stream().cuda_stream)
+            e.set_option(mod.OPT_TILE_SORT, tile_sort)
+            e.sort_from(t.data_ptr(), n, pay.data_ptr())
+            k, p = e.download(want_perm=True)
+            assert np.array_equal(k, np.sort(keys)) and np.array_equal(p, np.argsort(keys, kind="stable").astype(np.uint32))
+            assert np.array_equal(t.cpu().numpy().view(keys.dtype), keys)
+            for first, last in ((0, 3), (2, 3), (1, bits // 4), (0, bits // 4 - 1)):
+                out = torch.zeros(n + 9, dtype=t.dtype, device="cuda")
+                pout = torch.zeros(n + 9, dtype=torch.int32, device="cuda")
+                e.set_option(mod.OPT_FIRST_PASS, 0)
+                e.sort_from_to(t.data_ptr(), n, first, last, out[3:].data_ptr(), pay.data_ptr(), pout[3:].data_ptr())
+                torch.cuda.synchronize()
+                field = (u >> u.dtype.type(4 * first)) & u.dtype.type((1 << (4 * (last - first))) - 1)
+                order = np.argsort(field, kind="stable")
+                got = out.cpu().numpy().view(keys.dtype)
+                assert np.array_equal(got[3:3 + n], keys[order]) and not got[:3].any() and not got[3 + n:].any(), (tile_sort, first, last)
+                assert np.array_equal(pout.cpu().numpy().view(np.uint32)[3:3 + n], order.astype(np.uint32))
+            # internal sorts: the result buffer alternates as in the chain, and sorting the result again is the identity
+            e.sort_from(t.data_ptr(), n, pay.data_ptr())
+            for _ in range(3):
+                dk, dp = e.result_device()
+                e.sort_from(dk, n, dp)
+            k2, p2 = e.download(want_perm=True)
+            assert np.array_equal(k2, k) and np.array_equal(p2, p)
+
+
 # --------------------------------------------------------------------------- aliasing and stale state
 def test_sort_from_accepts_the_engines_own_result_buffer(mod, oracle):
     """rsx_sort_from on the pointer rsx_result_device just returned (one of the engine's ping-pong

@@ -1,15 +1,14 @@
 #!/bin/bash
-# Mkeys/s over sizes 2^16..2^30 (uint32 Random, device-resident) -> $1
-OUT=${1:-gpurun_out/size_sweep.jsonl}
-: > $OUT
-for lg in 16 18 20 22 24 26 28 30; do
-  steps=20; [ $lg -ge 30 ] && steps=5
-  python bench.py --steps $steps --warmup 2 --no-cpu-baseline --log2-keys $lg >> $OUT 2>> ${OUT%.jsonl}.err || echo "{\"failed\": $lg}" >> $OUT
+# size_sweep.sh [out.jsonl] [sizes...]: one bench line per input size (no HIP events inside the timed region: at small sizes they cost as much as a launch)
+OUT=${1:-gpurun_out/size_sweep.jsonl}; shift
+SIZES=${@:-"8 10 12 14 16 18 20 22 24 26 28"}
+: > "$OUT"
+for p in $SIZES; do
+  python bench.py --log2-keys $p --steps $([ $p -le 22 ] && echo 200 || echo 30) --warmup 5 --no-events --no-cpu-baseline 2>/dev/null | tail -1 >> "$OUT"
 done
-python - <<PY
-import json
-for l in open("$OUT"):
-    d=json.loads(l)
-    if 'failed' in d: print(d); continue
-    print("2^%-3d %10.1f Mkeys/s  %9.4f ms/sort  reorder %.4f ms (%4.1f%% of peak)" % (d['config']['keys_per_gpu'].bit_length()-1, d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'], 100*d['roofline']['frac']))
+python - "$OUT" <<'PY'
+import json, sys
+for l in open(sys.argv[1]):
+    d = json.loads(l)
+    print(f"{d['config']['workload']:<48} {d['ms_per_step']:9.4f} ms/sort {d['value']:10.1f} Mkeys/s")
 PY
