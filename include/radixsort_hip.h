@@ -70,6 +70,9 @@ typedef enum rsx_option {
     RSX_OPT_TILE_SORT = 8,    /* 1 (default): inside rsx_sort, inputs of at most one tile (4096 keys) are sorted by ONE workgroup in
                                  ONE launch, every pass inside LDS; buffers, table and group sums end up as the pass chain
                                  leaves them.  Not taken while RSX_OPT_PROFILE is 1 (per-launch timings of the steps). */
+    RSX_OPT_FUSED_SCAN = 9,   /* 1 (default): inside rsx_sort, tables of up to 1024 scan groups (2^30 keys) are scanned and pasted in
+                                 ONE launch whose workgroups hand their group sums to each other through tagged 8-byte
+                                 granules; 0: scan #1, then scan #2 + paste (two launches).  Same table either way. */
     RSX_OPT_LOOKAHEAD = 4     /* 1 (default): inside rsx_sort the reorder of pass p also counts pass p+1's digits per
                                  output tile, so only the first pass runs the histogram kernel; 0: every pass runs
                                  histogram -> scan -> paste -> reorder separately.  Results are identical. */

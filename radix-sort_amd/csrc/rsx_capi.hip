@@ -117,6 +117,11 @@ struct rsx_engine {
     uint32_t* globsum2 = nullptr;               // their scanned copy when scan #2 ran inside the paste
     uint32_t* globsum_live = nullptr;           // which of the two a download should read
     int paste_scan = 1;                         // rsx_sort: scan #2 + paste in one launch (env RSX_PASTE_SCAN)
+    int fused_scan = 1;                         // rsx_sort: scan #1, scan #2 and paste in ONE launch, arrival counter inside (env RSX_FUSED_SCAN)
+    unsigned long long* gsums = nullptr;        // fused scan: {epoch, raw group sum} granules [group][16]
+    uint32_t* scan_timeout = nullptr;           // fused scan: set by a workgroup whose poll ran out (device) ...
+    uint32_t* scan_timeout_host = nullptr;      // ... and its pinned mirror, checked in rsx_sync / rsx_download
+    uint32_t scan_epoch = 0;                    // launch count of the fused scan (tags the granules; never 0)
     uint32_t* temp = nullptr;                   // grand total of scan #2
     uint32_t* counts_next = nullptr;            // look-ahead histogram of the next pass, [tile][digit]
 #ifdef RSX_STAMPS
@@ -302,6 +307,34 @@ int launch_paste_scan(rsx_engine* e, uint64_t count)
                        ntiles, ngroups);
     RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
     return RSX_OK;
+}
+
+// rsx_sort only: scan #1, scan #2 and paste in ONE launch (all its workgroups resident at once; an arrival counter in
+// global memory stands where the two kernel boundaries stood).  Returns true when it took the pass.
+bool launch_scan_fused(rsx_engine* e, uint64_t count, bool from_counts, int* rc)
+{
+    const uint32_t ntiles = static_cast<uint32_t>(e->ntiles(count));
+    const uint32_t ngroups = (ntiles + rsx::kScanTiles - 1) / rsx::kScanTiles;
+    // (a captured graph would replay a stale epoch: the graph path keeps the separate launches)
+    if (!e->fused_scan || e->use_graph || count == 0 || ngroups > static_cast<uint32_t>(rsx::kFusedScanMaxGroups)) return false;
+    e->counted_keys = nullptr;
+    e->globsum_live = e->globsum2;
+    if (++e->scan_epoch == 0) e->scan_epoch = 1;
+    {
+        Bracket b(e, PH_SCAN);
+        if (from_counts && e->scan_zeroes) {
+            hipLaunchKernelGGL((rsx::scan_fused_kernel<true, true>), dim3(ngroups), dim3(rsx::kScanTiles), 0, e->stream, e->table, e->gsums, e->globsum2, e->temp,
+                               ntiles, ngroups, e->counts_next, e->scan_epoch, e->scan_timeout);
+        } else if (from_counts) {
+            hipLaunchKernelGGL((rsx::scan_fused_kernel<true, false>), dim3(ngroups), dim3(rsx::kScanTiles), 0, e->stream, e->table, e->gsums, e->globsum2, e->temp,
+                               ntiles, ngroups, e->counts_next, e->scan_epoch, e->scan_timeout);
+        } else {
+            hipLaunchKernelGGL((rsx::scan_fused_kernel<false, false>), dim3(ngroups), dim3(rsx::kScanTiles), 0, e->stream, e->table, e->gsums, e->globsum2, e->temp,
+                               ntiles, ngroups, e->counts_next, e->scan_epoch, e->scan_timeout);
+        }
+    }
+    *rc = hipGetLastError() == hipSuccess ? RSX_OK : fail(RSX_CALCULATION_FAILED, "scan_fused_kernel launch");
+    return true;
 }
 
 // rsx_sort only: tables of at most 1024 tiles (2^22 keys) are scanned AND pasted by one workgroup
@@ -513,6 +546,7 @@ int sort_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext_
             rc = first ? launch_histogram<Key>(e, in, count, shift, RSX_RADIX - 1) : RSX_OK;
             bool pasted = false;
             if (rc == RSX_OK) pasted = launch_scan_small(e, count, /*from_counts=*/!first, &rc);
+            if (rc == RSX_OK && !pasted && !e->fold_paste) pasted = launch_scan_fused(e, count, /*from_counts=*/!first, &rc);
             const bool merged = e->paste_scan && !e->fold_paste;     // scan #2 inside the paste launch
             if (rc == RSX_OK && !pasted) rc = launch_scan(e, count, /*from_counts=*/!first, /*scan_level2=*/!merged);
             // small tables were scanned and pasted in one launch; otherwise the paste kernel runs
@@ -610,6 +644,15 @@ int sort_chain(rsx_engine* e, const void* ext_keys, const uint32_t* ext_perm, ui
     return RSX_OK;
 }
 
+// a fused-scan workgroup whose poll ran out leaves a flag: surfaced at the host's next synchronisation point
+int check_scan_timeout(rsx_engine* e, int status)
+{
+    if (e->scan_epoch == 0) return RSX_OK;
+    RSX_TRY(hipMemcpyAsync(e->scan_timeout_host, e->scan_timeout, 4, hipMemcpyDeviceToHost, e->stream), status);
+    RSX_TRY(hipStreamSynchronize(e->stream), status);
+    if (e->scan_timeout_host[0] != 0) return fail(status, "the fused table scan timed out waiting for a group sum (result undefined)");
+    return RSX_OK;
+}
 bool aligned16(const void* p)
 {
     return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
@@ -711,6 +754,7 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
     if (const char* env = std::getenv("RSX_SMALL_SCAN")) e->small_scan = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_TILE_SORT")) e->tile_sort = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_PASTE_SCAN")) e->paste_scan = std::atoi(env) != 0;
+    if (const char* env = std::getenv("RSX_FUSED_SCAN")) e->fused_scan = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_FOLD_PASTE")) e->fold_paste = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_SCAN_ZEROES")) e->scan_zeroes = std::atoi(env) != 0;
 
@@ -755,6 +799,17 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
     e->globsum_live = e->globsum;
     if ((err = hipMalloc(reinterpret_cast<void**>(&e->temp), 64)) != hipSuccess)
         return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(temp)", err);
+    if ((err = hipMalloc(reinterpret_cast<void**>(&e->gsums), rsx::kFusedScanMaxGroups * RSX_RADIX * 8)) != hipSuccess)
+        return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(group sums)", err);
+    if ((err = hipMemsetAsync(e->gsums, 0, rsx::kFusedScanMaxGroups * RSX_RADIX * 8, e->stream)) != hipSuccess)
+        return bail(RSX_INITIALIZATION_FAILED, "hipMemsetAsync(group sums)", err);
+    if ((err = hipMalloc(reinterpret_cast<void**>(&e->scan_timeout), 64)) != hipSuccess)
+        return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(scan timeout flag)", err);
+    if ((err = hipMemsetAsync(e->scan_timeout, 0, 64, e->stream)) != hipSuccess)
+        return bail(RSX_INITIALIZATION_FAILED, "hipMemsetAsync(scan timeout flag)", err);
+    if ((err = hipHostMalloc(reinterpret_cast<void**>(&e->scan_timeout_host), 64, hipHostMallocDefault)) != hipSuccess)
+        return bail(RSX_HOST_BUFFERS_FAILED, "hipHostMalloc(scan timeout flag)", err);
+    e->scan_timeout_host[0] = 0;
     if ((err = hipMalloc(reinterpret_cast<void**>(&e->ref_table), rsx::kRefTable * 4)) != hipSuccess)
         return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(ref table)", err);
     if ((err = hipMalloc(reinterpret_cast<void**>(&e->ref_globsum), rsx::kRefSplit * 4)) != hipSuccess)
@@ -824,6 +879,9 @@ int rsx_destroy(rsx_engine* e)
     if (e->globsum && hipFree(e->globsum) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->globsum2 && hipFree(e->globsum2) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->temp && hipFree(e->temp) != hipSuccess) status = RSX_CLEANUP_FAILED;
+    if (e->gsums && hipFree(e->gsums) != hipSuccess) status = RSX_CLEANUP_FAILED;
+    if (e->scan_timeout && hipFree(e->scan_timeout) != hipSuccess) status = RSX_CLEANUP_FAILED;
+    if (e->scan_timeout_host && hipHostFree(e->scan_timeout_host) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->starts_dev && hipFree(e->starts_dev) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->range_dev && hipFree(e->range_dev) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->ref_table && hipFree(e->ref_table) != hipSuccess) status = RSX_CLEANUP_FAILED;
@@ -869,6 +927,7 @@ int rsx_set_option(rsx_engine* e, int option, int64_t value)
     case RSX_OPT_GRAPH: e->use_graph = value != 0; return RSX_OK;
     case RSX_OPT_SMALL_SCAN: e->small_scan = value != 0; return RSX_OK;
     case RSX_OPT_TILE_SORT: e->tile_sort = value != 0; return RSX_OK;
+    case RSX_OPT_FUSED_SCAN: e->fused_scan = value != 0; return RSX_OK;
     case RSX_OPT_FIRST_PASS:
         if (value < 0 || value > e->passes()) return fail(RSX_CALCULATION_FAILED, "rsx_set_option: first pass out of range");
         e->first_pass = static_cast<int>(value);
@@ -957,6 +1016,7 @@ int rsx_download(rsx_engine* e, void* host_keys_out, uint32_t* host_perm_out, ui
 {
     if (!e) return fail(RSX_DATA_DOWNLOAD_FAILED, "rsx_download: null engine");
     if (bind_device(e, RSX_DATA_DOWNLOAD_FAILED) != RSX_OK) return RSX_DATA_DOWNLOAD_FAILED;
+    if (check_scan_timeout(e, RSX_DATA_DOWNLOAD_FAILED) != RSX_OK) return RSX_DATA_DOWNLOAD_FAILED;
     if (e->result_external && e->n > 0 && (host_keys_out || host_perm_out))
         return fail(RSX_DATA_DOWNLOAD_FAILED, "rsx_download: the last sort (rsx_sort_from_to) wrote into the caller's buffer; the engine holds no result");
     if (e->n > 0 && host_keys_out) {
@@ -1075,7 +1135,7 @@ int rsx_sync(rsx_engine* e)
     if (!e) return fail(RSX_CALCULATION_FAILED, "rsx_sync: null engine");
     if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
     RSX_TRY(hipStreamSynchronize(e->stream), RSX_CALCULATION_FAILED);
-    return RSX_OK;
+    return check_scan_timeout(e, RSX_CALCULATION_FAILED);
 }
 
 int rsx_sort_from(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n)

@@ -451,6 +451,154 @@ __global__ __launch_bounds__(kScanTiles) void paste_scan_kernel(uint32_t* __rest
     }
 }
 
+// scan #1, scan #2 and paste in ONE launch for tables of up to kFusedScanMaxGroups groups (all of its workgroups
+// are then resident at once).  Every workgroup scans its 256 tiles per digit as scan_blocks_kernel does and
+// KEEPS the block-local prefixes in registers.  Its 16 group sums leave as 8-byte {epoch, value} granules —
+// one aligned write-through (agent-scope, sc1) store each, the data is its own flag — into sums[group][16];
+// then every workgroup sweeps ALL granules with agent-scope loads, re-reading a granule until its tag is
+// this launch's epoch (relaxed polls with s_sleep, bounded), derives its 16 global offsets and writes the
+// finished table once.  Both sides of the hand-off bypass the non-coherent L1/L2 path, so no release/acquire
+// fence (which would write back the 8 MiB of counters just zeroed) is needed, and a granule of an earlier
+// launch can never be taken for a current one.  Against the two-launch form this drops a kernel boundary,
+// the table's second read and write, and the 32 wave scans of the paste.  `epoch` is the engine's launch
+// count (never 0).  A poll that runs out sets *timeout and lets the workgroup finish with garbage rather
+// than hang the GPU (rsx_sync / rsx_download report it).
+constexpr int kFusedScanMaxGroups = 1024;     // 2^30 keys; 256-thread workgroups, <= 4 per CU: all resident
+typedef __attribute__((address_space(1))) uint32_t gu32;
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+
+template <bool FROM_COUNTS, bool ZERO_BACK>
+__global__ __launch_bounds__(kScanTiles) void scan_fused_kernel(uint32_t* __restrict__ table, unsigned long long* sums, uint32_t* __restrict__ scanned,
+                                                                 uint32_t* __restrict__ temp, uint32_t ntiles, uint32_t ngroups,
+                                                                 uint32_t* __restrict__ counts, uint32_t epoch, uint32_t* timeout)
+{
+    constexpr int WAVES = kScanTiles / kWave;
+    __shared__ uint32_t wsum[WAVES][kRadix];
+    __shared__ uint32_t part[WAVES][2][kRadix];
+    __shared__ uint32_t dtot[kRadix], off[kRadix];
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    const uint32_t group = blockIdx.x;
+    const uint32_t tile = group * kScanTiles + tid;
+    const bool live = tile < ntiles;
+    uint32_t c[kRadix];
+    if constexpr (FROM_COUNTS) {
+        U32x4* row = reinterpret_cast<U32x4*>(counts + static_cast<uint64_t>(tile) * kRadix);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            U32x4 x = {{0u, 0u, 0u, 0u}};
+            if (live) {
+                x = row[q];
+                if constexpr (ZERO_BACK) {
+                    row[q] = U32x4{{0u, 0u, 0u, 0u}};
+                }
+            }
+            c[q * 4 + 0] = x.v[0];
+            c[q * 4 + 1] = x.v[1];
+            c[q * 4 + 2] = x.v[2];
+            c[q * 4 + 3] = x.v[3];
+        }
+    } else {
+#pragma unroll
+        for (int d = 0; d < kRadix; ++d) {
+            c[d] = live ? table[static_cast<uint64_t>(d) * ntiles + tile] : 0u;
+        }
+    }
+    uint32_t ex[kRadix];          // block-local exclusive prefix of this tile, per digit (stays in registers)
+#pragma unroll
+    for (int d = 0; d < kRadix; ++d) {
+        ex[d] = wave_inclusive_scan(c[d]);
+    }
+    if (lane == kWave - 1) {
+#pragma unroll
+        for (int d = 0; d < kRadix; ++d) {
+            wsum[wave][d] = ex[d];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < kRadix; ++d) {
+        uint32_t before = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            before += (static_cast<uint32_t>(w) < wave) ? wsum[w][d] : 0u;
+        }
+        ex[d] = before + ex[d] - c[d];
+    }
+    // ---- publish the 16 group sums as {epoch, value} granules ---------------------------------------
+    if (tid < kRadix) {
+        uint32_t total = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            total += wsum[w][tid];
+        }
+        __hip_atomic_store((gu64*)(sums) + static_cast<uint64_t>(group) * kRadix + tid, (static_cast<unsigned long long>(epoch) << 32) | total,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- sweep all group sums -> the 16 global offsets of this group ---------------------------------
+    // thread (digit d = tid & 15, slice p = tid >> 4) walks the groups p, p+16, ...: a wave reads 4 whole
+    // 128-byte rows per load; a granule whose tag is not yet this launch's is simply read again
+    {
+        const uint32_t d = tid & 15u, p = tid >> 4;
+        uint32_t tot = 0, pre = 0, spins = 0;
+        for (uint32_t g2 = p; g2 < ngroups; g2 += kScanTiles / kRadix) {
+            unsigned long long x = __hip_atomic_load((gu64*)(sums) + static_cast<uint64_t>(g2) * kRadix + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (static_cast<uint32_t>(x >> 32) != epoch) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 22)) {              // seconds: something is badly wrong; do not hang the device
+                    __hip_atomic_store((gu32*)(timeout), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                x = __hip_atomic_load((gu64*)(sums) + static_cast<uint64_t>(g2) * kRadix + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const uint32_t v = static_cast<uint32_t>(x);
+            tot += v;
+            pre += (g2 < group) ? v : 0u;
+        }
+        tot += __shfl_xor(tot, 16);
+        pre += __shfl_xor(pre, 16);
+        tot += __shfl_xor(tot, 32);
+        pre += __shfl_xor(pre, 32);
+        if (lane < kRadix) {
+            part[wave][0][lane] = tot;
+            part[wave][1][lane] = pre;
+        }
+    }
+    __syncthreads();
+    if (tid < kRadix) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            t += part[w][0][tid];
+        }
+        dtot[tid] = t;
+    }
+    __syncthreads();
+    if (tid < kRadix) {
+        uint32_t base = 0;
+#pragma unroll 1
+        for (uint32_t d2 = 0; d2 < tid; ++d2) {
+            base += dtot[d2];
+        }
+        uint32_t pr = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            pr += part[w][1][tid];
+        }
+        off[tid] = base + pr;
+        scanned[static_cast<uint64_t>(tid) * ngroups + group] = base + pr;
+        if (group == 0 && tid == kRadix - 1) {
+            temp[0] = base + dtot[tid];
+        }
+    }
+    __syncthreads();
+    if (live) {
+#pragma unroll
+        for (int d = 0; d < kRadix; ++d) {
+            table[static_cast<uint64_t>(d) * ntiles + tile] = ex[d] + off[d];
+        }
+    }
+}
+
 // Whole table scan in ONE workgroup — scan #1, scan #2 and paste of a small table in a single
 // launch.  Up to 2^22 keys a pass is so short that the three tiny kernels above and their launch
 // boundaries (~15 us together) dominate it; one 1024-thread workgroup walks a table of at most

@@ -418,6 +418,34 @@ def test_config5_inputs_2pow26_bit_exact_vs_oracle(mod, oracle, kind):
     assert np.array_equal(_sort(mod, keys), oracle.radix_sort(keys))
 
 
+# --------------------------------------------------------------------------- table scan variants
+@pytest.mark.parametrize("dt,payload", [("uint32", False), ("int64", True)])
+@pytest.mark.parametrize("n", [5000, 300001, (1 << 22) + 17, (1 << 24) + 4097])
+def test_fused_scan_equals_the_separate_launches(mod, oracle, dt, payload, n):
+    """The one-launch table scan (group sums handed over as tagged granules inside the launch) against scan #1 +
+    scan #2/paste as separate launches: same keys, same payload, same final table and group sums."""
+    keys = oracle.dataset("SeededUniform", dt, n, seed=n)
+    perm = np.arange(n, dtype=np.uint32) if payload else None
+    seen = []
+    for fused, small in ((1, 0), (0, 0), (1, 1)):
+        with mod.Engine(dt, n, payload=payload) as e:
+            e.set_option(mod.OPT_FUSED_SCAN, fused)
+            e.set_option(mod.OPT_SMALL_SCAN, small)
+            e.upload(keys, perm)
+            for _ in range(3):                    # epochs advance; granules of earlier launches must never be taken for current ones
+                e.sort()
+            g = e.geometry()
+            out = e.download(want_perm=payload, hist_cap=int(g.table_len), globsum_cap=int(g.num_scan_blocks))
+            seen.append(out if isinstance(out, tuple) else (out,))
+    want = np.sort(keys)
+    for got in seen:
+        assert np.array_equal(got[0], want)
+    for a, b in zip(seen[0], seen[1]):            # fused vs separate launches: everything, incl. table and group sums
+        assert np.array_equal(a, b)
+    for a, b in zip(seen[0][:-1], seen[2][:-1]):  # the one-workgroup scan of small tables leaves no group sums
+        assert np.array_equal(a, b)
+
+
 # --------------------------------------------------------------------------- one-workgroup sort of small inputs
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("n", [1, 2, 17, 1000, 1024, 4095, 4096])
