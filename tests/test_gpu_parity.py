@@ -279,6 +279,12 @@ def test_timings_profile_mode(mod, oracle):
         e.upload(keys)
         e.sort()
         t = e.timings(reset=True)
+        assert t.histogram.n == 1 and t.reorder.n == 8 and t.paste.n == 0 and t.scan.n == 8      # the fused scan: one launch per pass
+        assert np.array_equal(e.download(), np.sort(keys))
+        e.set_option(mod.OPT_FUSED_SCAN, 0)
+        e.upload(keys)
+        e.sort()
+        t = e.timings(reset=True)
         assert t.histogram.n == 1 and t.reorder.n == 8 and t.paste.n == 8      # scan #1, then scan #2 + paste in one launch
         assert t.scan.n == 8
         assert np.array_equal(e.download(), np.sort(keys))
