@@ -156,6 +156,22 @@ int rsx_download(rsx_engine* e, void* host_keys_out, uint32_t* host_perm_out,
 int rsx_pin_host(rsx_engine* e, void* host_ptr, uint64_t bytes);
 int rsx_unpin_host(rsx_engine* e, void* host_ptr);
 
+/* End-to-end beyond one upload -> sort -> download at a time (the reference's avgTotalGPU column pays for all
+ * three in sequence, src/CRadixSortTask.cpp:357-378; its visualizer sorts straight out of mapped host memory,
+ * examples/visualize/visualize.cpp:801-854).
+ * rsx_pipeline_submit: asynchronous.  Copies n keys (and permutation) from host memory into a device inbox on an
+ *   upload stream, sorts them behind that copy on the engine's stream, and copies the result to host_keys_out on a
+ *   download stream.  Two jobs are in flight at once (two inboxes, two outboxes, allocated on first use): the
+ *   upload of job i+1 and the download of job i-1 run beside the sort of job i.  Host buffers must stay untouched
+ *   until rsx_pipeline_wait and should be pinned (rsx_pin_host), otherwise the copies serialise on the host.
+ * rsx_pipeline_wait: waits for every submitted job.
+ * rsx_host_device_pointer: the device-side address of pinned (rsx_pin_host) host memory, for the zero-copy form:
+ *   rsx_sort_from_to(e, <that address>, ...) reads the keys over PCIe in its first pass (and histogram) and
+ *   writes its last pass straight into mapped host memory. */
+int rsx_pipeline_submit(rsx_engine* e, const void* host_keys, const uint32_t* host_perm, uint64_t n, void* host_keys_out, uint32_t* host_perm_out);
+int rsx_pipeline_wait(rsx_engine* e);
+int rsx_host_device_pointer(rsx_engine* e, void* host_ptr, void** device_ptr);
+
 /* ---- the hot path, step by step ---------------------------------------------
  * Asynchronous on the engine's stream; no host synchronisation inside.
  * rsx_histogram = RadixSortGPU::Histogram        (src/RadixSortGPU.cpp:16-61)

@@ -36,7 +36,7 @@ OPT_PROFILE, OPT_XCD_REMAP, OPT_FIRST_PASS, OPT_LAST_PASS, OPT_LOOKAHEAD, OPT_RE
 SYMBOLS = [
     "rsx_device_count", "rsx_device_name", "rsx_last_error", "rsx_version",
     "rsx_create", "rsx_destroy", "rsx_set_stream", "rsx_get_stream", "rsx_set_option", "rsx_get_geometry", "rsx_resize",
-    "rsx_upload", "rsx_fill_pad", "rsx_download", "rsx_pin_host", "rsx_unpin_host",
+    "rsx_upload", "rsx_fill_pad", "rsx_download", "rsx_pin_host", "rsx_unpin_host", "rsx_pipeline_submit", "rsx_pipeline_wait", "rsx_host_device_pointer",
     "rsx_histogram", "rsx_scan", "rsx_paste", "rsx_reorder", "rsx_sort", "rsx_sync",
     "rsx_sort_from", "rsx_partition", "rsx_partition_count", "rsx_partition_scatter", "rsx_sample_keys", "rsx_partition_count_split", "rsx_partition_scatter_split", "rsx_partition_count_waves", "rsx_partition_scatter_waves", "rsx_sort_from_to", "rsx_key_range", "rsx_partition_range", "rsx_result_device", "rsx_copy_result", "rsx_timings",
 ]
@@ -119,6 +119,9 @@ def load_library() -> C.CDLL:
         "rsx_download": ([P, P, P, P, U64, P, U64], I),
         "rsx_pin_host": ([P, P, U64], I),
         "rsx_unpin_host": ([P, P], I),
+        "rsx_pipeline_submit": ([P, P, P, U64, P, P], I),
+        "rsx_pipeline_wait": ([P], I),
+        "rsx_host_device_pointer": ([P, P, C.POINTER(P)], I),
         "rsx_histogram": ([P, I], I),
         "rsx_scan": ([P], I),
         "rsx_paste": ([P], I),
@@ -238,6 +241,20 @@ class Engine:
 
     def unpin_host(self, arr: np.ndarray) -> None:
         self._check(self.lib.rsx_unpin_host(self._h, arr.ctypes.data), "rsx_unpin_host")
+
+    def pipeline_submit(self, keys: np.ndarray, out: np.ndarray, perm: np.ndarray | None = None, perm_out: np.ndarray | None = None) -> None:
+        """Asynchronous upload -> sort -> download of one job; `keys`/`out` (pinned) must stay alive and untouched until pipeline_wait()."""
+        assert keys.dtype == self.dtype and out.dtype == self.dtype and out.size >= keys.size and keys.flags.c_contiguous and out.flags.c_contiguous
+        self._check(self.lib.rsx_pipeline_submit(self._h, keys.ctypes.data, perm.ctypes.data if perm is not None else None, keys.size,
+                                                 out.ctypes.data, perm_out.ctypes.data if perm_out is not None else None), "rsx_pipeline_submit")
+
+    def pipeline_wait(self) -> None:
+        self._check(self.lib.rsx_pipeline_wait(self._h), "rsx_pipeline_wait")
+
+    def host_device_pointer(self, arr: np.ndarray) -> int:
+        p = C.c_void_p()
+        self._check(self.lib.rsx_host_device_pointer(self._h, arr.ctypes.data, C.byref(p)), "rsx_host_device_pointer")
+        return int(p.value or 0)
 
     def fill_pad(self, byte_offset: int) -> None:
         self._check(self.lib.rsx_fill_pad(self._h, byte_offset), "rsx_fill_pad")

@@ -151,6 +151,19 @@ struct rsx_engine {
     hipStream_t stream = nullptr;
     bool own_stream = false;
 
+    // end-to-end pipeline (rsx_pipeline_submit): two jobs in flight, each with its own device inbox and outbox,
+    // uploads and downloads on streams of their own beside the sort stream
+    struct Pipeline {
+        bool ready = false;
+        void* in[2] = {nullptr, nullptr};
+        void* out[2] = {nullptr, nullptr};
+        uint32_t* pin[2] = {nullptr, nullptr};
+        uint32_t* pout[2] = {nullptr, nullptr};
+        hipStream_t s_in = nullptr, s_out = nullptr;
+        hipEvent_t in_ready[2] = {nullptr, nullptr}, sorted[2] = {nullptr, nullptr}, out_done[2] = {nullptr, nullptr};
+        uint64_t submitted = 0;
+    } pipe;
+
     int profile = 0;            // 0 off, 1 every launch, 2 reorder launches (+ whole sort) only
     int xcd_remap = 1;
     int reverse_odd = 0;                        // odd passes walk the tiles backwards (env RSX_REVERSE_ODD; measured, see the tuning log)
@@ -888,6 +901,19 @@ int rsx_destroy(rsx_engine* e)
     if (e->ref_globsum && hipFree(e->ref_globsum) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->range_host && hipHostFree(e->range_host) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->starts_host && hipHostFree(e->starts_host) != hipSuccess) status = RSX_CLEANUP_FAILED;
+    if (e->pipe.s_in) (void)hipStreamSynchronize(e->pipe.s_in);
+    if (e->pipe.s_out) (void)hipStreamSynchronize(e->pipe.s_out);
+    for (int i = 0; i < 2; ++i) {
+        if (e->pipe.in[i] && hipFree(e->pipe.in[i]) != hipSuccess) status = RSX_CLEANUP_FAILED;
+        if (e->pipe.out[i] && hipFree(e->pipe.out[i]) != hipSuccess) status = RSX_CLEANUP_FAILED;
+        if (e->pipe.pin[i] && hipFree(e->pipe.pin[i]) != hipSuccess) status = RSX_CLEANUP_FAILED;
+        if (e->pipe.pout[i] && hipFree(e->pipe.pout[i]) != hipSuccess) status = RSX_CLEANUP_FAILED;
+        if (e->pipe.in_ready[i]) (void)hipEventDestroy(e->pipe.in_ready[i]);
+        if (e->pipe.sorted[i]) (void)hipEventDestroy(e->pipe.sorted[i]);
+        if (e->pipe.out_done[i]) (void)hipEventDestroy(e->pipe.out_done[i]);
+    }
+    if (e->pipe.s_in && hipStreamDestroy(e->pipe.s_in) != hipSuccess) status = RSX_CLEANUP_FAILED;
+    if (e->pipe.s_out && hipStreamDestroy(e->pipe.s_out) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->own_stream && e->stream && hipStreamDestroy(e->stream) != hipSuccess) status = RSX_CLEANUP_FAILED;
     delete e;
     return status;
@@ -1070,7 +1096,7 @@ int rsx_pin_host(rsx_engine* e, void* host_ptr, uint64_t bytes)
 {
     if (!e || !host_ptr || bytes == 0) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_pin_host: null argument");
     if (bind_device(e, RSX_HOST_BUFFERS_FAILED) != RSX_OK) return RSX_HOST_BUFFERS_FAILED;
-    RSX_TRY(hipHostRegister(host_ptr, static_cast<size_t>(bytes), hipHostRegisterDefault), RSX_HOST_BUFFERS_FAILED);
+    RSX_TRY(hipHostRegister(host_ptr, static_cast<size_t>(bytes), hipHostRegisterMapped), RSX_HOST_BUFFERS_FAILED);
     return RSX_OK;
 }
 
@@ -1080,6 +1106,81 @@ int rsx_unpin_host(rsx_engine* e, void* host_ptr)
     if (bind_device(e, RSX_HOST_BUFFERS_FAILED) != RSX_OK) return RSX_HOST_BUFFERS_FAILED;
     RSX_TRY(hipHostUnregister(host_ptr), RSX_HOST_BUFFERS_FAILED);
     return RSX_OK;
+}
+
+int rsx_host_device_pointer(rsx_engine* e, void* host_ptr, void** device_ptr)
+{
+    if (!e || !host_ptr || !device_ptr) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_host_device_pointer: null argument");
+    if (bind_device(e, RSX_HOST_BUFFERS_FAILED) != RSX_OK) return RSX_HOST_BUFFERS_FAILED;
+    RSX_TRY(hipHostGetDevicePointer(device_ptr, host_ptr, 0), RSX_HOST_BUFFERS_FAILED);
+    return RSX_OK;
+}
+
+namespace {
+int pipeline_init(rsx_engine* e)
+{
+    rsx_engine::Pipeline& p = e->pipe;
+    if (p.ready) return RSX_OK;
+    const size_t key_buf = static_cast<size_t>(e->capacity) * e->key_bytes;
+    for (int i = 0; i < 2; ++i) {
+        RSX_TRY(hipMalloc(&p.in[i], key_buf), RSX_INITIALIZATION_FAILED);
+        RSX_TRY(hipMalloc(&p.out[i], key_buf), RSX_INITIALIZATION_FAILED);
+        if (e->has_payload) {
+            RSX_TRY(hipMalloc(reinterpret_cast<void**>(&p.pin[i]), static_cast<size_t>(e->capacity) * 4), RSX_INITIALIZATION_FAILED);
+            RSX_TRY(hipMalloc(reinterpret_cast<void**>(&p.pout[i]), static_cast<size_t>(e->capacity) * 4), RSX_INITIALIZATION_FAILED);
+        }
+        RSX_TRY(hipEventCreateWithFlags(&p.in_ready[i], hipEventDisableTiming), RSX_INITIALIZATION_FAILED);
+        RSX_TRY(hipEventCreateWithFlags(&p.sorted[i], hipEventDisableTiming), RSX_INITIALIZATION_FAILED);
+        RSX_TRY(hipEventCreateWithFlags(&p.out_done[i], hipEventDisableTiming), RSX_INITIALIZATION_FAILED);
+    }
+    RSX_TRY(hipStreamCreateWithFlags(&p.s_in, hipStreamNonBlocking), RSX_INITIALIZATION_FAILED);
+    RSX_TRY(hipStreamCreateWithFlags(&p.s_out, hipStreamNonBlocking), RSX_INITIALIZATION_FAILED);
+    p.ready = true;
+    return RSX_OK;
+}
+}  // namespace
+
+int rsx_pipeline_submit(rsx_engine* e, const void* host_keys, const uint32_t* host_perm, uint64_t n, void* host_keys_out, uint32_t* host_perm_out)
+{
+    if (!e) return fail(RSX_CALCULATION_FAILED, "rsx_pipeline_submit: null engine");
+    if (n == 0 || n > e->capacity) return fail(RSX_RESIZE_FAILED, "rsx_pipeline_submit: key count must be in [1, capacity]");
+    if (!host_keys || !host_keys_out) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_pipeline_submit: null host buffer");
+    if (e->has_payload && (!host_perm || !host_perm_out)) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_pipeline_submit: payload engine needs permutation buffers");
+    if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
+    int rc = pipeline_init(e);
+    if (rc != RSX_OK) return rc;
+    rsx_engine::Pipeline& p = e->pipe;
+    const int s = static_cast<int>(p.submitted & 1u);
+    const size_t kb = static_cast<size_t>(n) * e->key_bytes;
+    // upload: the inbox is free once the job two submissions ago has been sorted out of it
+    if (p.submitted >= 2) RSX_TRY(hipStreamWaitEvent(p.s_in, p.sorted[s], 0), RSX_DATA_UPLOAD_FAILED);
+    RSX_TRY(hipMemcpyAsync(p.in[s], host_keys, kb, hipMemcpyHostToDevice, p.s_in), RSX_DATA_UPLOAD_FAILED);
+    if (e->has_payload) RSX_TRY(hipMemcpyAsync(p.pin[s], host_perm, static_cast<size_t>(n) * 4, hipMemcpyHostToDevice, p.s_in), RSX_DATA_UPLOAD_FAILED);
+    RSX_TRY(hipEventRecord(p.in_ready[s], p.s_in), RSX_DATA_UPLOAD_FAILED);
+    // sort: behind its upload, and behind the download that last read this outbox
+    RSX_TRY(hipStreamWaitEvent(e->stream, p.in_ready[s], 0), RSX_CALCULATION_FAILED);
+    if (p.submitted >= 2) RSX_TRY(hipStreamWaitEvent(e->stream, p.out_done[s], 0), RSX_CALCULATION_FAILED);
+    rc = rsx_sort_from_to(e, p.in[s], p.pin[s], n, 0, static_cast<int>(e->passes()), p.out[s], p.pout[s]);
+    if (rc != RSX_OK) return rc;
+    RSX_TRY(hipEventRecord(p.sorted[s], e->stream), RSX_CALCULATION_FAILED);
+    // download
+    RSX_TRY(hipStreamWaitEvent(p.s_out, p.sorted[s], 0), RSX_DATA_DOWNLOAD_FAILED);
+    RSX_TRY(hipMemcpyAsync(host_keys_out, p.out[s], kb, hipMemcpyDeviceToHost, p.s_out), RSX_DATA_DOWNLOAD_FAILED);
+    if (e->has_payload) RSX_TRY(hipMemcpyAsync(host_perm_out, p.pout[s], static_cast<size_t>(n) * 4, hipMemcpyDeviceToHost, p.s_out), RSX_DATA_DOWNLOAD_FAILED);
+    RSX_TRY(hipEventRecord(p.out_done[s], p.s_out), RSX_DATA_DOWNLOAD_FAILED);
+    p.submitted += 1;
+    return RSX_OK;
+}
+
+int rsx_pipeline_wait(rsx_engine* e)
+{
+    if (!e) return fail(RSX_DATA_DOWNLOAD_FAILED, "rsx_pipeline_wait: null engine");
+    if (!e->pipe.ready) return RSX_OK;
+    if (bind_device(e, RSX_DATA_DOWNLOAD_FAILED) != RSX_OK) return RSX_DATA_DOWNLOAD_FAILED;
+    RSX_TRY(hipStreamSynchronize(e->pipe.s_in), RSX_DATA_DOWNLOAD_FAILED);
+    RSX_TRY(hipStreamSynchronize(e->stream), RSX_DATA_DOWNLOAD_FAILED);
+    RSX_TRY(hipStreamSynchronize(e->pipe.s_out), RSX_DATA_DOWNLOAD_FAILED);
+    return check_scan_timeout(e, RSX_DATA_DOWNLOAD_FAILED);
 }
 
 int rsx_histogram(rsx_engine* e, int pass)

@@ -75,4 +75,6 @@ protected:
     std::uint32_t mNumberKeysRounded{0U};         ///< what is uploaded, sorted and downloaded
     double mAvgTotalGPUms{0.0};
     bool mExecutionFailed{false};
+    std::vector<DataType> mSecondResult{};        ///< --overlap: odd submissions download here
+    std::vector<std::uint32_t> mFirstPermOut{}, mSecondPermOut{};
 };

@@ -76,6 +76,8 @@ template <typename DataType>
 OperationStatus RadixSortGPU<DataType>::release()
 {
     if (!mEngine) return OperationStatus::OK;
+    for (void* p : mExtraPinned) rsx_unpin_host(mEngine, p);
+    mExtraPinned.clear();
     if (mPinned) {
         rsx_unpin_host(mEngine, mHostSpans.m_hKeys.data());
         rsx_unpin_host(mEngine, mHostSpans.m_hResultFromGPU.data());
@@ -229,6 +231,53 @@ OperationStatus RadixSortGPU<DataType>::calculate(hipc::CommandQueue CommandQueu
     }
     // timeTotal.avg = sum of the per-launch averages, n = histogram sample count
     // (src/RadixSortGPU.cpp:337-343) — kept, although it is not a per-sort time.
+    mRuntimesGPU.timeTotal.avg = mRuntimesGPU.timeHisto.avg + mRuntimesGPU.timeScan.avg + mRuntimesGPU.timeReorder.avg + mRuntimesGPU.timePaste.avg;
+    mRuntimesGPU.timeTotal.n = mRuntimesGPU.timeHisto.n;
+    return mLastStatus == RSX_OK ? OperationStatus::OK : OperationStatus::CALCULATION_FAILED;
+}
+
+template <typename DataType>
+OperationStatus RadixSortGPU<DataType>::pinExtra(void* ptr, std::uint64_t bytes)
+{
+    if (!mEngine || rsx_pin_host(mEngine, ptr, bytes) != RSX_OK) return OperationStatus::HOST_BUFFERS_FAILED;
+    mExtraPinned.push_back(ptr);
+    return OperationStatus::OK;
+}
+
+template <typename DataType>
+OperationStatus RadixSortGPU<DataType>::submitOverlapped(DataType* resultOut, std::uint32_t* permutationOut)
+{
+    if (!mEngine || !mPinned || !resultOut) return OperationStatus::HOST_BUFFERS_FAILED;
+    mLastStatus = rsx_pipeline_submit(mEngine, mHostSpans.m_hKeys.data(), mWithPermutation ? mHostSpans.h_Permut.data() : nullptr, mNumberKeysRounded,
+                                      resultOut, mWithPermutation ? permutationOut : nullptr);
+    return mLastStatus == RSX_OK ? OperationStatus::OK : static_cast<OperationStatus>(mLastStatus);
+}
+
+template <typename DataType>
+OperationStatus RadixSortGPU<DataType>::waitOverlapped()
+{
+    if (!mEngine) return OperationStatus::DATA_DOWNLOAD_FAILED;
+    mLastStatus = rsx_pipeline_wait(mEngine);
+    if (mLastStatus == RSX_OK) foldEventTimings();
+    mRuntimesGPU.timeTotal.avg = mRuntimesGPU.timeHisto.avg + mRuntimesGPU.timeScan.avg + mRuntimesGPU.timeReorder.avg + mRuntimesGPU.timePaste.avg;
+    mRuntimesGPU.timeTotal.n = mRuntimesGPU.timeHisto.n;
+    return mLastStatus == RSX_OK ? OperationStatus::OK : OperationStatus::DATA_DOWNLOAD_FAILED;
+}
+
+template <typename DataType>
+OperationStatus RadixSortGPU<DataType>::calculateZeroCopy(hipc::CommandQueue CommandQueue, std::uint32_t* permutationOut)
+{
+    if (!bindQueue(CommandQueue) || !mPinned || (mWithPermutation && !permutationOut)) return OperationStatus::HOST_BUFFERS_FAILED;
+    void *dIn = nullptr, *dOut = nullptr, *dPin = nullptr, *dPout = nullptr;
+    mLastStatus = rsx_host_device_pointer(mEngine, mHostSpans.m_hKeys.data(), &dIn);
+    if (mLastStatus == RSX_OK) mLastStatus = rsx_host_device_pointer(mEngine, mHostSpans.m_hResultFromGPU.data(), &dOut);
+    if (mLastStatus == RSX_OK && mWithPermutation) mLastStatus = rsx_host_device_pointer(mEngine, mHostSpans.h_Permut.data(), &dPin);
+    if (mLastStatus == RSX_OK && mWithPermutation) mLastStatus = rsx_host_device_pointer(mEngine, permutationOut, &dPout);
+    if (mLastStatus != RSX_OK) return OperationStatus::HOST_BUFFERS_FAILED;
+    mLastStatus = rsx_sort_from_to(mEngine, dIn, static_cast<const std::uint32_t*>(dPin), mNumberKeysRounded, 0, static_cast<int>(Parameters::_NUM_PASSES), dOut,
+                                   static_cast<std::uint32_t*>(dPout));
+    if (mLastStatus == RSX_OK) mLastStatus = rsx_sync(mEngine);
+    if (mLastStatus == RSX_OK) foldEventTimings();
     mRuntimesGPU.timeTotal.avg = mRuntimesGPU.timeHisto.avg + mRuntimesGPU.timeScan.avg + mRuntimesGPU.timeReorder.avg + mRuntimesGPU.timePaste.avg;
     mRuntimesGPU.timeTotal.n = mRuntimesGPU.timeHisto.n;
     return mLastStatus == RSX_OK ? OperationStatus::OK : OperationStatus::CALCULATION_FAILED;

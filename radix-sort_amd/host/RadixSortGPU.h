@@ -13,6 +13,7 @@
 //     followed by a stream sync and timed with the host stopwatch — the reference's own
 //     accounting (src/RadixSortGPU.cpp:38-56,89-108,128-147,171-190,242-255).
 #pragma once
+#include <vector>
 
 #include "Common/ComputeState.h"
 #include "HostData.h"
@@ -63,6 +64,19 @@ public:
     /// at src/ComputeDeviceData.cpp:26).  Call before initialize().
     void enablePinnedTransfers(bool on) noexcept { mPinHost = on; }
     std::uint32_t numberKeysRounded() const noexcept { return mNumberKeysRounded; }
+    /// End to end, overlapped: one asynchronous uploadData -> calculate -> downloadData whose copies run on streams of
+    /// their own, so that with two submissions in flight the upload of the next sort and the download of the previous
+    /// one hide behind the current one (the reference runs the three strictly in sequence,
+    /// src/CRadixSortTask.cpp:289-314).  The result lands in `resultOut` (rounded length; pinned memory or the copies
+    /// serialise); waitOverlapped() returns when everything submitted has landed.  Needs enablePinnedTransfers(true).
+    OperationStatus submitOverlapped(DataType* resultOut, std::uint32_t* permutationOut = nullptr);
+    OperationStatus waitOverlapped();
+    /// Page-locks an additional caller buffer for the engine's lifetime (a second result buffer for submitOverlapped).
+    OperationStatus pinExtra(void* ptr, std::uint64_t bytes);
+    /// Zero copy (the reference's visualizer sorts out of mapped host memory, examples/visualize/visualize.cpp:801-854):
+    /// the first pass reads the pinned key span over PCIe, the last pass writes m_hResultFromGPU directly; no
+    /// uploadData / downloadData around it.  Needs enablePinnedTransfers(true).
+    OperationStatus calculateZeroCopy(hipc::CommandQueue CommandQueue, std::uint32_t* permutationOut = nullptr);   ///< permutationOut: pinned (pinExtra), required with enablePermutation
 
 private:
     using Parameters = AlgorithmParameters<DataType>;
@@ -85,5 +99,6 @@ private:
     bool mStepwise{false};
     bool mPinHost{false};
     bool mPinned{false};
+    std::vector<void*> mExtraPinned{};
     int mLastStatus{RSX_OK};
 };

@@ -24,6 +24,8 @@ struct RadixSortOptions {
     bool stepwise{false};           ///< --stepwise: sync + host-time every launch like the reference
     bool skip_cpu{false};           ///< --skip-cpu: no CPU referees (large sizes); validation uses sortedness
     bool pinned{false};             ///< --pinned: page-lock the host key/result buffers for the transfers
+    bool overlap{false};            ///< --overlap: the timed loop keeps two sorts in flight (upload / sort / download on three streams); implies --pinned
+    bool zero_copy{false};          ///< --zero-copy: the timed loop sorts straight out of / into mapped host memory; implies --pinned
 
     explicit RadixSortOptions(const std::vector<std::string>& args = {})
         : num_elements(AlgorithmParameters<float>::_NUM_MAX_INPUT_ELEMS)   // default 2^25 (src/RadixSortOptions.h:18)
@@ -43,6 +45,8 @@ struct RadixSortOptions {
             {"--stepwise", &RadixSortOptions::stepwise},
             {"--skip-cpu", &RadixSortOptions::skip_cpu},
             {"--pinned", &RadixSortOptions::pinned},
+            {"--overlap", &RadixSortOptions::overlap},
+            {"--zero-copy", &RadixSortOptions::zero_copy},
         };
         for (auto it = args.begin(); it != args.end(); ++it) {
             if (*it == "--num-elements") {
@@ -54,5 +58,6 @@ struct RadixSortOptions {
                 if (*it == sw.spelling) this->*sw.flag = true;
             }
         }
+        if (overlap || zero_copy) pinned = true;
     }
 };

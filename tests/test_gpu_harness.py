@@ -66,3 +66,41 @@ def test_pinned_transfers_and_sweep_csv(tmp_path):
     lines = out.read_text().strip().splitlines()
     assert lines[0].startswith("NumElements,Datatype,Dataset,avgHistogram,avgScan,avgPaste,avgReorder,avgTotalGPU,avgTotalSTLCPU,avgTotalRDXCPU")
     assert len(lines) == 1 + 3 * 20 and lines[1].startswith("4096,uint32_t,Zeros,")
+
+
+@pytest.mark.parametrize("mode", ["--overlap", "--zero-copy"])
+@pytest.mark.parametrize("n", [3000, (1 << 20) + 5])
+def test_overlapped_and_zero_copy_timed_loops(mode, n):
+    """End to end beyond upload -> sort -> download in sequence (reference: src/CRadixSortTask.cpp:357-378 times exactly
+    that sequence; examples/visualize/visualize.cpp:801-854 sorts out of mapped memory): --overlap keeps two sorts in
+    flight on three streams, --zero-copy sorts straight out of / into pinned host memory.  Every result — both
+    alternating download buffers, and the array the last pass wrote into host memory — is validated."""
+    proc = _run([os.path.join(BIN, "rsx_tests"), "--num-elements", str(n), mode, "--with-permutation", "--perf-to-stdout"])
+    assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-2000:]
+    assert "20/20 task runs validated" in proc.stdout and "FAILED" not in proc.stdout
+    assert proc.stdout.count("Validation of GPU permutation (stable argsort) has passed") == 20
+
+
+def test_pipeline_submit_through_the_binding():
+    """rsx_pipeline_submit / rsx_pipeline_wait from Python: six jobs of different inputs through two slots."""
+    import sys
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as entry
+    m = entry.load_package()
+    n = 500003
+    rng = np.random.default_rng(9)
+    with m.Engine("int32", n, payload=True) as e:
+        ins = [rng.integers(-2**31, 2**31 - 1, size=n, dtype=np.int32) for _ in range(6)]
+        outs = [np.empty(n, dtype=np.int32) for _ in range(6)]
+        perm = np.arange(n, dtype=np.uint32)
+        pouts = [np.empty(n, dtype=np.uint32) for _ in range(6)]
+        for a in ins + outs + pouts + [perm]:
+            e.pin_host(a)
+        for k, o, po in zip(ins, outs, pouts):
+            e.pipeline_submit(k, o, perm, po)
+        e.pipeline_wait()
+        for k, o, po in zip(ins, outs, pouts):
+            assert np.array_equal(o, np.sort(k)) and np.array_equal(po, np.argsort(k, kind="stable").astype(np.uint32))
+        for a in ins + outs + pouts + [perm]:
+            e.unpin_host(a)
