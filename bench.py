@@ -143,6 +143,7 @@ def parse_args(argv=None):
     ap.add_argument("--payload", action="store_true", help="carry a uint32 payload (h_Permut)")
     ap.add_argument("--dataset", default="Random", choices=list(KIND_CODES))
     ap.add_argument("--cpu-sample-log2", type=int, default=None, help="CPU baseline sample = first 2^this keys of rank 0's input (default: 28 at N=1 = the whole workload, ~13 s; 26 at N>1)")
+    ap.add_argument("--radix-bits", type=int, default=4, choices=[4, 8], help="digit width: 4 = the reference's configuration and the headline; 8 = half the passes, reported as a separate row")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-verify-full", action="store_true", help="N>1: skip the gather of all outputs on rank 0 and keep only the checksum / boundary checks")
@@ -223,6 +224,8 @@ def main() -> None:
     # timed region: HIP events bracket only the graded reorder launches (8 pairs per sort);
     # the per-phase table below comes from a fully instrumented step after it
     eng.set_option(rsx.OPT_PROFILE, 0 if args.no_events else 2)
+    if args.radix_bits != 4:
+        eng.set_option(rsx.OPT_RADIX_BITS, args.radix_bits)
     sorter = ShardedSorter(eng, rank, world, key_bytes * 8, dist, force_exchange=force_exchange, strategy=os.environ.get("RSX_STRATEGY", "auto"))
     staging = recv = spay = rpay = obuf = opay = None
     if sharded:
@@ -347,7 +350,7 @@ def main() -> None:
     # algorithmic bytes of one reorder launch: n*(K+V) read + n*(K+V) written.
     # N>1: launches differ in size (the partition pass sees n keys, the local passes what arrived,
     # wave by wave on the pipelined path), so the figure is bytes of all launches / time of all launches
-    passes = key_bytes * 2
+    passes = key_bytes * 8 // args.radix_bits
     if sharded:
         local_passes = passes - 1 if sorter.last_path == "waves" else passes
         scatter_bytes_per_step = 2.0 * (key_bytes + pay_bytes) * (n + local_passes * n_local)
@@ -358,10 +361,10 @@ def main() -> None:
 
     def pow2(v):
         return f"2^{v.bit_length() - 1}" if v & (v - 1) == 0 else str(v)
-    workload = f"{pow2(n)} {args.dtype}{'+u32 payload' if args.payload else ''} {kind}, 4-bit digits, {passes} passes"
+    workload = f"{pow2(n)} {args.dtype}{'+u32 payload' if args.payload else ''} {kind}, {args.radix_bits}-bit digits, {passes} passes"
     if world > 1:
-        workload = f"{pow2(total_keys)} {args.dtype}{'+u32 payload' if args.payload else ''} keys sharded {world}x ({pow2(n)} per GPU, {kind}), RCCL histogram all-gather + key all-to-all over xGMI, 4-bit digits"
-        if total_keys == 1 << 30 and args.dtype == "uint32" and not args.payload:
+        workload = f"{pow2(total_keys)} {args.dtype}{'+u32 payload' if args.payload else ''} keys sharded {world}x ({pow2(n)} per GPU, {kind}), RCCL histogram all-gather + key all-to-all over xGMI, {args.radix_bits}-bit digits"
+        if total_keys == 1 << 30 and args.dtype == "uint32" and not args.payload and args.radix_bits == 4:
             workload += " [BASELINE config 4]"
     line = {
         "metric": METRIC,
@@ -387,6 +390,8 @@ def main() -> None:
     }
     if exchange_ms is not None:
         line["sharded_phases_ms"] = dict(exchange_ms, note="rank 0, device time between marks of one instrumented step after the timed region")
+    if args.radix_bits != 4:
+        line["config"]["note"] = "8-bit digits: a separately reported variant; BASELINE's configuration is 4-bit digits"
     if base_entry is not None:
         line["cpu_baseline"] = base_entry
     if rehearsal:

@@ -73,6 +73,11 @@ typedef enum rsx_option {
     RSX_OPT_FUSED_SCAN = 9,   /* 1 (default): inside rsx_sort, tables of up to 1024 scan groups (2^30 keys) are scanned and pasted in
                                  ONE launch whose workgroups hand their group sums to each other through tagged 8-byte
                                  granules; 0: scan #1, then scan #2 + paste (two launches).  Same table either way. */
+    RSX_OPT_RADIX_BITS = 10,  /* digit width of the rsx_sort chain: 4 (default, the reference's _NUM_BITS_PER_RADIX, src/Parameters.h:25) or 8.
+                                 With 8 a pass sorts by a whole byte (two stable 4-bit rounds inside LDS, one scatter of up to
+                                 256 runs per tile): half the passes over HBM.  Same result.  Pass ranges (RSX_OPT_FIRST_PASS /
+                                 LAST_PASS, rsx_sort_from_to) stay in units of 4-bit passes and must cover whole bytes, otherwise
+                                 the 4-bit chain runs; the step API and the diagnostic tables are those of 4-bit passes. */
     RSX_OPT_LOOKAHEAD = 4     /* 1 (default): inside rsx_sort the reorder of pass p also counts pass p+1's digits per
                                  output tile, so only the first pass runs the histogram kernel; 0: every pass runs
                                  histogram -> scan -> paste -> reorder separately.  Results are identical. */

@@ -169,6 +169,10 @@ struct rsx_engine {
     int reverse_odd = 0;                        // odd passes walk the tiles backwards (env RSX_REVERSE_ODD; measured, see the tuning log)
     int lookahead = 1;          // rsx_sort builds pass p+1's histogram inside pass p's reorder
     int small_scan = 1;         // rsx_sort: one-workgroup scan+paste for tables of <= 1024 tiles (env RSX_SMALL_SCAN)
+    int radix_bits = 4;         // RSX_OPT_RADIX_BITS: 4 (the reference's configuration) or 8 (half the passes; rsx_sort chain only)
+    uint32_t* counts8 = nullptr;                // 8-bit digits: raw counts [tile][256] (allocated on first use)
+    uint32_t* table8 = nullptr;                 //   group-local exclusive prefixes [tile][256]
+    uint32_t* gsum8 = nullptr;                  //   per scan group: totals, then global first slots [group][256]
     int tile_sort = 1;          // rsx_sort: inputs of at most one tile are sorted by ONE workgroup in ONE launch, all passes in LDS (env RSX_TILE_SORT)
     int fold_paste = 0;         // reorder adds globsum itself (no paste launch): measured 3 % slower, off; env RSX_FOLD_PASTE
     int scan_zeroes = 1;
@@ -528,9 +532,87 @@ int sort_tile_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext_p
     return RSX_OK;
 }
 
+// 8-bit digits: per pass histogram8 -> scan8 (two launches) -> reorder8, half as many passes.  Taken by the sort
+// chain when RSX_OPT_RADIX_BITS is 8 and the pass range [first_pass, last_pass) — counted in 4-bit passes, as
+// everywhere in this API — covers whole bytes.
+template <typename Key>
+int sort8_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext_perm, uint64_t count)
+{
+    using L = rsx::Reorder8Layout<Key, kTileThreads, kKeysPerThread>;
+    const Grid g = grid_for(e, count);
+    const uint32_t ngroups = (g.ntiles + rsx::kScan8Tiles - 1) / rsx::kScan8Tiles;
+    if (!e->counts8) {
+        const size_t rows = static_cast<size_t>(e->ntiles(e->capacity)) * rsx::kRadix8 * 4;
+        const size_t groups = ((e->ntiles(e->capacity) + rsx::kScan8Tiles - 1) / rsx::kScan8Tiles) * rsx::kRadix8 * 4;
+        RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->counts8), rows), RSX_INITIALIZATION_FAILED);
+        RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->table8), rows), RSX_INITIALIZATION_FAILED);
+        RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->gsum8), groups), RSX_INITIALIZATION_FAILED);
+        RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L::BYTES)), RSX_INITIALIZATION_FAILED);
+        RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L::BYTES)), RSX_INITIALIZATION_FAILED);
+    }
+    const void* in = ext_keys ? ext_keys : e->keys[e->cur];
+    const uint32_t* pin = e->has_payload ? (ext_keys ? ext_perm : e->perm[e->cur]) : nullptr;
+    int dst = ext_keys ? e->cur : (e->cur ^ 1);
+    Bracket whole(e, PH_TOTAL);
+    e->counted_keys = nullptr;
+    const Key flip = flip_mask<Key>(e);
+    for (int pass = e->first_pass; pass < e->last_pass; pass += 2) {
+        const bool to_caller = e->final_keys_out && pass + 2 == e->last_pass;
+        void* out = to_caller ? e->final_keys_out : e->keys[dst];
+        uint32_t* pout = e->has_payload ? (to_caller ? e->final_perm_out : e->perm[dst]) : nullptr;
+        const int shift = pass * RSX_RADIX_BITS;
+        {
+            Bracket b(e, PH_HISTO);
+            hipLaunchKernelGGL((rsx::histogram8_kernel<Key, kTileThreads, kKeysPerThread>), dim3(g.blocks), dim3(kTileThreads), 0, e->stream,
+                               static_cast<const Key*>(in), e->counts8, count, g.ntiles, g.tiles_per_xcd, e->xcd_remap, shift, flip);
+        }
+        {
+            Bracket b(e, PH_SCAN);
+            hipLaunchKernelGGL(rsx::scan8_blocks_kernel, dim3(ngroups), dim3(rsx::kRadix8), 0, e->stream, e->counts8, e->table8, e->gsum8, g.ntiles);
+        }
+        {
+            Bracket b(e, PH_SCAN);
+            hipLaunchKernelGGL(rsx::scan8_groups_kernel, dim3(1), dim3(rsx::kScan8Threads), 0, e->stream, e->gsum8, e->temp, ngroups);
+        }
+        {
+            Bracket b(e, PH_REORDER);
+            if (e->has_payload) {
+                hipLaunchKernelGGL((rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, true>), dim3(g.blocks), dim3(kTileThreads), L::BYTES, e->stream,
+                                   static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->counts8, e->table8, e->gsum8, count, g.ntiles,
+                                   g.tiles_per_xcd, e->xcd_remap, shift, flip);
+            } else {
+                hipLaunchKernelGGL((rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, false>), dim3(g.blocks), dim3(kTileThreads), L::BYTES, e->stream,
+                                   static_cast<const Key*>(in), static_cast<Key*>(out), nullptr, nullptr, e->counts8, e->table8, e->gsum8, count, g.ntiles,
+                                   g.tiles_per_xcd, e->xcd_remap, shift, flip);
+            }
+        }
+        RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
+        e->last_in = in;
+        e->last_shift = shift + RSX_RADIX_BITS;       // (the reference-geometry diagnostics are those of 4-bit passes; not meaningful here)
+        in = out;
+        pin = pout;
+        dst ^= 1;
+    }
+    if (in == e->keys[0] || in == e->keys[1]) e->cur = (in == e->keys[0]) ? 0 : 1;
+    e->result_external = e->final_keys_out != nullptr;
+    if (e->final_keys_out) {
+        e->result_keys = e->final_keys_out;
+        e->result_perm = e->has_payload ? e->final_perm_out : nullptr;
+    } else {
+        e->result_keys = e->keys[e->cur];
+        e->result_perm = e->has_payload ? e->perm[e->cur] : nullptr;
+    }
+    return RSX_OK;
+}
+
 template <typename Key>
 int sort_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext_perm, uint64_t count)
 {
+    if (e->radix_bits == 8 && count > static_cast<uint64_t>(kTileKeys) && e->first_pass < e->last_pass && (e->first_pass & 1) == 0 && (e->last_pass & 1) == 0) {
+        return sort8_chain_enqueue<Key>(e, ext_keys, ext_perm, count);
+    }
     if (e->tile_sort && e->profile != 1 && count > 0 && count <= static_cast<uint64_t>(kTileKeys) && e->first_pass < e->last_pass) {
         return sort_tile_enqueue<Key>(e, ext_keys, ext_perm, count);
     }
@@ -766,6 +848,7 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
     if (const char* env = std::getenv("RSX_GRAPH")) e->use_graph = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_SMALL_SCAN")) e->small_scan = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_TILE_SORT")) e->tile_sort = std::atoi(env) != 0;
+    if (const char* env = std::getenv("RSX_RADIX_BITS")) e->radix_bits = std::atoi(env) == 8 ? 8 : 4;
     if (const char* env = std::getenv("RSX_PASTE_SCAN")) e->paste_scan = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_FUSED_SCAN")) e->fused_scan = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_FOLD_PASTE")) e->fold_paste = std::atoi(env) != 0;
@@ -893,6 +976,9 @@ int rsx_destroy(rsx_engine* e)
     if (e->globsum2 && hipFree(e->globsum2) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->temp && hipFree(e->temp) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->gsums && hipFree(e->gsums) != hipSuccess) status = RSX_CLEANUP_FAILED;
+    if (e->counts8 && hipFree(e->counts8) != hipSuccess) status = RSX_CLEANUP_FAILED;
+    if (e->table8 && hipFree(e->table8) != hipSuccess) status = RSX_CLEANUP_FAILED;
+    if (e->gsum8 && hipFree(e->gsum8) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->scan_timeout && hipFree(e->scan_timeout) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->scan_timeout_host && hipHostFree(e->scan_timeout_host) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->starts_dev && hipFree(e->starts_dev) != hipSuccess) status = RSX_CLEANUP_FAILED;
@@ -954,6 +1040,10 @@ int rsx_set_option(rsx_engine* e, int option, int64_t value)
     case RSX_OPT_SMALL_SCAN: e->small_scan = value != 0; return RSX_OK;
     case RSX_OPT_TILE_SORT: e->tile_sort = value != 0; return RSX_OK;
     case RSX_OPT_FUSED_SCAN: e->fused_scan = value != 0; return RSX_OK;
+    case RSX_OPT_RADIX_BITS:
+        if (value != 4 && value != 8) return fail(RSX_CALCULATION_FAILED, "rsx_set_option: digit width must be 4 or 8 bits");
+        e->radix_bits = static_cast<int>(value);
+        return RSX_OK;
     case RSX_OPT_FIRST_PASS:
         if (value < 0 || value > e->passes()) return fail(RSX_CALCULATION_FAILED, "rsx_set_option: first pass out of range");
         e->first_pass = static_cast<int>(value);

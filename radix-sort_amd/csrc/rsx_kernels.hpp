@@ -1445,6 +1445,358 @@ __global__ __launch_bounds__(THREADS) void tile_sort_kernel(const Key* in, Key* 
 }
 
 // ---------------------------------------------------------------------------
+// 8-bit digits: half the passes (RSX_OPT_RADIX_BITS = 8, reported separately from the 4-bit configuration)
+// ---------------------------------------------------------------------------
+// The reference's digit width is a parameter (_NUM_BITS_PER_RADIX, src/Parameters.h:25, pushed into the kernels at
+// src/RadixSortGPU.cpp:569-584).  A pass over an 8-bit digit is built from the 4-bit machinery above: the tile is
+// sorted locally by the low nibble and then by the high nibble of the digit — two stable rounds through LDS, the
+// second one starting from 16 consecutive keys of the first one's order per thread — and leaves as up to 256 runs.
+// Tables are [tile][256] (a tile's 256 counters are one contiguous 1 KiB row):
+//   histogram8_kernel   counts8[tile][d]   = keys of the tile with digit d
+//   scan8_blocks_kernel table8[tile][d]    = keys with digit d in EARLIER tiles of the tile's group (G tiles); gsum8[group][d] = group total
+//   scan8_groups_kernel gsum8[group][d]    = global slot of the first key of (digit d, group): all smaller digits + earlier groups
+//   reorder8_kernel     slot of a key      = gsum8[group][d] + table8[tile][d] + (its rank inside the tile's run of digit d)
+constexpr int kRadix8 = 256;
+constexpr int kScan8Tiles = 64;               // tiles per scan group
+constexpr int kScan8Threads = 1024;           // scan8_groups_kernel: 256 digits x 4 slices of the groups
+
+template <typename Key>
+__device__ __forceinline__ uint32_t digit8_of(Key key, int shift, Key flip)
+{
+    return static_cast<uint32_t>((key ^ flip) >> shift) & 255u;
+}
+
+template <typename Key, int THREADS, int KPT>
+__global__ __launch_bounds__(THREADS) void histogram8_kernel(const Key* __restrict__ keys, uint32_t* __restrict__ counts8, uint64_t n, uint32_t ntiles,
+                                                              uint32_t tiles_per_xcd, int remap, int shift, Key flip)
+{
+    static_assert(THREADS == kRadix8, "one thread per digit writes the tile's row");
+    constexpr int TILE = THREADS * KPT;
+    constexpr int VEC = KeyVec<Key>::N;
+    constexpr int NV = KPT / VEC;
+    __shared__ uint32_t cnt[kRadix8];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t tile = tile_of_block(blockIdx.x, tiles_per_xcd, remap);
+    if (tile >= ntiles) {
+        return;
+    }
+    cnt[tid] = 0;
+    __syncthreads();
+    const uint64_t base = static_cast<uint64_t>(tile) * TILE;
+    const uint64_t left = n - base;
+    const uint32_t valid = left < static_cast<uint64_t>(TILE) ? static_cast<uint32_t>(left) : static_cast<uint32_t>(TILE);
+    if (valid == TILE) {
+        KeyVec<Key> v[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            v[j] = *reinterpret_cast<const KeyVec<Key>*>(keys + base + static_cast<uint32_t>(j) * THREADS * VEC + tid * VEC);
+        }
+        // a wave whose keys all share the digit (constant or sorted data) would serialise 64 lanes on one LDS
+        // address per key: the first key stands for the wave, as in reorder_kernel's look-ahead
+        const uint32_t d0 = digit8_of(v[0].k[0], shift, flip);
+        const bool spread = __ballot(d0 != static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(d0)))) != 0ull;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const uint32_t d = digit8_of(v[j].k[e], shift, flip);
+                if (spread) {
+                    atomicAdd(&cnt[d], 1u);
+                } else {
+                    const uint32_t first = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(d)));
+                    if (__ballot(d != first) == 0ull) {
+                        if ((tid & (kWave - 1)) == 0) {
+                            atomicAdd(&cnt[first], static_cast<uint32_t>(kWave));
+                        }
+                    } else {
+                        atomicAdd(&cnt[d], 1u);
+                    }
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const uint32_t li = static_cast<uint32_t>(j) * THREADS * VEC + tid * VEC + e;
+                if (li < valid) {
+                    atomicAdd(&cnt[digit8_of(keys[base + li], shift, flip)], 1u);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    counts8[static_cast<uint64_t>(tile) * kRadix8 + tid] = cnt[tid];
+}
+
+// one workgroup per group of kScan8Tiles tiles; thread d walks the group's rows (1 KiB each, coalesced)
+__global__ __launch_bounds__(kRadix8) void scan8_blocks_kernel(const uint32_t* __restrict__ counts8, uint32_t* __restrict__ table8, uint32_t* __restrict__ gsum8,
+                                                                uint32_t ntiles)
+{
+    const uint32_t d = threadIdx.x, group = blockIdx.x;
+    const uint32_t t0 = group * kScan8Tiles;
+    const uint32_t t1 = t0 + kScan8Tiles < ntiles ? t0 + kScan8Tiles : ntiles;
+    uint32_t run = 0;
+    uint32_t t = t0;
+    for (; t + 8 <= t1; t += 8) {
+        uint32_t c[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            c[u] = counts8[static_cast<uint64_t>(t + u) * kRadix8 + d];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            table8[static_cast<uint64_t>(t + u) * kRadix8 + d] = run;
+            run += c[u];
+        }
+    }
+    for (; t < t1; ++t) {
+        const uint32_t c = counts8[static_cast<uint64_t>(t) * kRadix8 + d];
+        table8[static_cast<uint64_t>(t) * kRadix8 + d] = run;
+        run += c;
+    }
+    gsum8[static_cast<uint64_t>(group) * kRadix8 + d] = run;
+}
+
+// ONE workgroup: gsum8[group][d] (group totals) -> global slot of the first key of (digit d, group).  Thread
+// (slice q = tid >> 8, digit d = tid & 255) walks its quarter of the groups.
+__global__ __launch_bounds__(kScan8Threads) void scan8_groups_kernel(uint32_t* __restrict__ gsum8, uint32_t* __restrict__ temp, uint32_t ngroups)
+{
+    constexpr int SLICES = kScan8Threads / kRadix8;
+    __shared__ uint32_t slice_tot[SLICES][kRadix8];
+    __shared__ uint32_t wtot[kRadix8 / kWave];
+    __shared__ uint32_t digit_base[kRadix8];
+    const uint32_t tid = threadIdx.x, d = tid & (kRadix8 - 1), q = tid >> 8;
+    const uint32_t per = (ngroups + SLICES - 1) / SLICES;
+    const uint32_t g0 = q * per, g1 = (g0 + per < ngroups) ? g0 + per : ngroups;
+    uint32_t sum = 0;
+    for (uint32_t g = g0; g < g1; ++g) {
+        sum += gsum8[static_cast<uint64_t>(g) * kRadix8 + d];
+    }
+    slice_tot[q][d] = sum;
+    __syncthreads();
+    uint32_t total = 0, before_slices = 0;
+#pragma unroll
+    for (int s2 = 0; s2 < SLICES; ++s2) {
+        const uint32_t v = slice_tot[s2][d];
+        total += v;
+        before_slices += (static_cast<uint32_t>(s2) < q) ? v : 0u;
+    }
+    if (tid < kRadix8) {
+        uint32_t all;
+        const uint32_t base = block_exclusive_scan<kRadix8>(total, wtot, all);      // keys with a smaller digit
+        digit_base[d] = base;
+        if (tid == kRadix8 - 1) {
+            temp[0] = all;
+        }
+    }
+    __syncthreads();
+    uint32_t run = digit_base[d] + before_slices;
+    for (uint32_t g = g0; g < g1; ++g) {
+        const uint32_t c = gsum8[static_cast<uint64_t>(g) * kRadix8 + d];
+        gsum8[static_cast<uint64_t>(g) * kRadix8 + d] = run;
+        run += c;
+    }
+}
+
+template <typename Key, int THREADS, int KPT>
+struct Reorder8Layout {
+    static constexpr int KD = sizeof(Key) / 4;
+    static constexpr int ROW_DW = KPT * KD + 4;                 // as TileSortLayout: 16-byte aligned rows on distinct bank quads
+    static constexpr int XBUF_DW = THREADS * ROW_DW;
+    static constexpr int CNT_DW = 8 * THREADS;
+    static constexpr int TOTAL_DW = XBUF_DW + CNT_DW + 16 + kRadix8;
+    static constexpr size_t BYTES = static_cast<size_t>(TOTAL_DW) * 4;
+    static constexpr int WGS_PER_CU = static_cast<int>((160 * 1024) / BYTES);
+    static constexpr int MIN_WAVES = (WGS_PER_CU * THREADS / 256) > 8 ? 8 : (WGS_PER_CU * THREADS / 256);
+    static_assert(KPT == 16 && THREADS == kRadix8, "row geometry; one thread per digit handles the tile's table row");
+};
+
+template <typename Key, int THREADS, int KPT, bool PAYLOAD>
+__global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREADS, KPT>::MIN_WAVES > 4 ? 4 : Reorder8Layout<Key, THREADS, KPT>::MIN_WAVES))) void reorder8_kernel(
+    const Key* __restrict__ in, Key* __restrict__ out, const uint32_t* __restrict__ pin, uint32_t* __restrict__ pout,
+    const uint32_t* __restrict__ counts8, const uint32_t* __restrict__ table8, const uint32_t* __restrict__ gsum8, uint64_t n, uint32_t ntiles,
+    uint32_t tiles_per_xcd, int remap, int shift, Key flip)
+{
+    using L = Reorder8Layout<Key, THREADS, KPT>;
+    constexpr int TILE = THREADS * KPT;
+    constexpr int KD = L::KD;
+    constexpr int VEC = KeyVec<Key>::N;
+    constexpr int NV = KPT / VEC;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t* xbuf = smem;
+    uint32_t* cnt = smem + L::XBUF_DW;
+    uint32_t* wtot = cnt + L::CNT_DW;
+    uint32_t* gb = wtot + 16;                     // per 8-bit digit: (global slot of the tile's first key with it) - (its local slot)
+    const uint32_t tid = threadIdx.x;
+    const uint32_t tile = tile_of_block(blockIdx.x, tiles_per_xcd, remap & 1);
+    if (tile >= ntiles) {
+        return;
+    }
+    const uint64_t base = static_cast<uint64_t>(tile) * TILE;
+    const uint64_t left = n - base;
+    const uint32_t valid = left < static_cast<uint64_t>(TILE) ? static_cast<uint32_t>(left) : static_cast<uint32_t>(TILE);
+    const bool full = (valid == TILE);
+    const Key pad_key = static_cast<Key>(~flip);          // digit 255, behind every real key of the tile
+    auto image_dw = [](uint32_t s) { return s * KD + ((s >> 4) << 2); };
+
+    // this thread's digit of the tile's table row (latency hides under the key loads)
+    const uint32_t my_count = counts8[static_cast<uint64_t>(tile) * kRadix8 + tid];
+    const uint32_t my_first = table8[static_cast<uint64_t>(tile) * kRadix8 + tid] + gsum8[static_cast<uint64_t>(tile / kScan8Tiles) * kRadix8 + tid];
+
+    Key k[KPT];
+    uint32_t pl[PAYLOAD ? KPT : 1];
+    if (full) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const KeyVec<Key> v = *reinterpret_cast<const KeyVec<Key>*>(in + base + tid * KPT + j * VEC);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                k[j * VEC + e] = v.k[e];
+            }
+        }
+        if constexpr (PAYLOAD) {
+#pragma unroll
+            for (int q = 0; q < KPT / 4; ++q) {
+                const U32x4 x = *reinterpret_cast<const U32x4*>(pin + base + tid * KPT + q * 4);
+                pl[q * 4 + 0] = x.v[0];
+                pl[q * 4 + 1] = x.v[1];
+                pl[q * 4 + 2] = x.v[2];
+                pl[q * 4 + 3] = x.v[3];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const uint32_t li = tid * KPT + i;
+            k[i] = li < valid ? in[base + li] : pad_key;
+            if constexpr (PAYLOAD) {
+                pl[i] = li < valid ? pin[base + li] : 0u;
+            }
+        }
+    }
+    // local first slot of every digit = exclusive scan of the tile's 256 counts; gb = global first - local first
+    {
+        uint32_t all;
+        const uint32_t local_first = block_exclusive_scan<THREADS>(my_count, wtot, all);
+        gb[tid] = my_first - local_first;
+    }
+    u32_alias* cnt32 = reinterpret_cast<u32_alias*>(cnt);
+    const u16_alias* cnt16 = reinterpret_cast<const u16_alias*>(cnt);
+
+#pragma unroll 1
+    for (int round = 0; round < 2; ++round) {
+        const int rshift = shift + round * kRadixBits;
+        uint32_t slot[KPT], dg[KPT];
+        uint64_t seen = 0;
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            dg[i] = digit_of(k[i], rshift, flip, static_cast<uint32_t>(kRadix - 1));
+            const uint32_t sh4 = dg[i] << 2;
+            slot[i] = static_cast<uint32_t>(seen >> sh4) & 15u;
+            if (i + 1 < KPT) {
+                seen += 1ull << sh4;
+            }
+        }
+        const uint32_t seen_lo = static_cast<uint32_t>(seen), seen_hi = static_cast<uint32_t>(seen >> 32);
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+            cnt32[l * THREADS + tid] = __builtin_amdgcn_ubfe(seen_lo, 4u * l, 4u) | (__builtin_amdgcn_ubfe(seen_hi, 4u * l, 4u) << 16);
+        }
+        atomicAdd(cnt + (dg[KPT - 1] & 7u) * THREADS + tid, 1u << ((dg[KPT - 1] >> 3) * 16u));
+        __syncthreads();
+        {
+            U32x4 a = *reinterpret_cast<const U32x4*>(cnt + tid * 8);
+            U32x4 b = *reinterpret_cast<const U32x4*>(cnt + tid * 8 + 4);
+            const uint32_t sum = a.v[0] + a.v[1] + a.v[2] + a.v[3] + b.v[0] + b.v[1] + b.v[2] + b.v[3];
+            uint32_t total;
+            uint32_t run = block_exclusive_scan<THREADS>(sum, wtot, total);
+            run += total << 16;
+            uint32_t t;
+            t = a.v[0]; a.v[0] = run; run += t;
+            t = a.v[1]; a.v[1] = run; run += t;
+            t = a.v[2]; a.v[2] = run; run += t;
+            t = a.v[3]; a.v[3] = run; run += t;
+            t = b.v[0]; b.v[0] = run; run += t;
+            t = b.v[1]; b.v[1] = run; run += t;
+            t = b.v[2]; b.v[2] = run; run += t;
+            t = b.v[3]; b.v[3] = run;
+            *reinterpret_cast<U32x4*>(cnt + tid * 8) = a;
+            *reinterpret_cast<U32x4*>(cnt + tid * 8 + 4) = b;
+        }
+        __syncthreads();
+        {
+            uint32_t first_of_digit[KPT];
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                first_of_digit[i] = cnt16[(((dg[i] & 7u) * THREADS + tid) << 1) + (dg[i] >> 3)];
+            }
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                slot[i] += first_of_digit[i];
+            }
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                *reinterpret_cast<Key*>(xbuf + image_dw(slot[i])) = k[i];
+            }
+        }
+        __syncthreads();
+        if (round == 0) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const KeyVec<Key> v = *reinterpret_cast<const KeyVec<Key>*>(xbuf + tid * L::ROW_DW + j * 4);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    k[j * VEC + e] = v.k[e];
+                }
+            }
+        } else {
+            // leave as runs: slot i = r*THREADS + tid, its global slot = gb[digit] + i
+#pragma unroll
+            for (int r = 0; r < KPT; ++r) {
+                const uint32_t i = static_cast<uint32_t>(r) * THREADS + tid;
+                const Key key = *reinterpret_cast<const Key*>(xbuf + image_dw(i));
+                const uint32_t g = gb[digit8_of(key, shift, flip)] + i;
+                if (full || i < valid) {
+                    out[g] = key;
+                }
+                if constexpr (PAYLOAD) {
+                    dg[r] = g;                    // the payload of slot i follows to the same place
+                }
+            }
+        }
+        if constexpr (PAYLOAD) {
+            __syncthreads();           // every thread has taken its keys: the image carries the payload now
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                xbuf[slot[i] + ((slot[i] >> 4) << 2)] = pl[i];
+            }
+            __syncthreads();
+            if (round == 0) {
+#pragma unroll
+                for (int q = 0; q < KPT / 4; ++q) {
+                    const U32x4 x = *reinterpret_cast<const U32x4*>(xbuf + tid * (KPT + 4) + q * 4);
+                    pl[q * 4 + 0] = x.v[0];
+                    pl[q * 4 + 1] = x.v[1];
+                    pl[q * 4 + 2] = x.v[2];
+                    pl[q * 4 + 3] = x.v[3];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < KPT; ++r) {
+                    const uint32_t i = static_cast<uint32_t>(r) * THREADS + tid;
+                    if (full || i < valid) {
+                        pout[dg[r]] = xbuf[i + ((i >> 4) << 2)];
+                    }
+                }
+            }
+        }
+        __syncthreads();               // image and counters are free for the second round
+    }
+}
+
+// ---------------------------------------------------------------------------
 // small utility kernels
 // ---------------------------------------------------------------------------
 // Diagnostics in the REFERENCE's geometry (RadixSortGPU.cpp:412-428 downloads them after every

@@ -424,6 +424,85 @@ def test_config5_inputs_2pow26_bit_exact_vs_oracle(mod, oracle, kind):
     assert np.array_equal(_sort(mod, keys), oracle.radix_sort(keys))
 
 
+# --------------------------------------------------------------------------- digit width
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("kind", KINDS)
+def test_8bit_digits_match_oracle_4x5_matrix(mod, oracle, dt, kind):
+    """The digit width is a parameter of the reference (_NUM_BITS_PER_RADIX, src/Parameters.h:25); with 8-bit digits the
+    reference's own test matrix (tests/tests.cpp:18-27,83-87) must give the same bytes as with 4-bit digits."""
+    keys = oracle.dataset(kind, dt, (1 << 16) + 13)
+    with mod.Engine(dt, keys.size) as e:
+        e.set_option(mod.OPT_RADIX_BITS, 8)
+        e.upload(keys)
+        e.sort()
+        got = e.download()
+    assert np.array_equal(got, oracle.std_sort(keys))
+    if keys.max() == np.iinfo(dt).max:      # inside the oracle's correct domain (full round count)
+        assert np.array_equal(got, oracle.radix_sort(keys))
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("n", [4097, 5000, 8191, 12288, 100003, (1 << 20) + 77])
+def test_8bit_digits_ragged_sizes_and_payload(mod, oracle, dt, n):
+    rng = np.random.default_rng(n)
+    info = np.iinfo(dt)
+    keys = rng.integers(info.min, info.max, size=n, dtype=dt, endpoint=True)
+    keys[::5] = keys[3]                                # ties: the payload order is checked too
+    perm = np.arange(n, dtype=np.uint32)
+    with mod.Engine(dt, n, payload=True) as e:
+        e.set_option(mod.OPT_RADIX_BITS, 8)
+        e.upload(keys, perm)
+        e.sort()
+        k, p = e.download(want_perm=True)
+        assert np.array_equal(k, np.sort(keys)) and np.array_equal(p, np.argsort(keys, kind="stable").astype(np.uint32))
+        e.sort()                                       # again, from the other ping-pong buffer: identity
+        k2, p2 = e.download(want_perm=True)
+        assert np.array_equal(k2, k) and np.array_equal(p2, p)
+
+
+def test_8bit_digits_pass_ranges_external_buffers_and_golden(mod, oracle, golden):
+    import torch
+    for row in golden["datasets"]:
+        if row["n"] <= 4096:
+            continue
+        keys = oracle.dataset(row["kind"], row["dtype"], row["n"])
+        with mod.Engine(row["dtype"], keys.size) as e:
+            e.set_option(mod.OPT_RADIX_BITS, 8)
+            e.upload(keys)
+            e.sort()
+            assert oracle.digest(e.download()) == row["sorted_digest"], row
+    n = 70001
+    keys = oracle.dataset("SeededUniform", "int64", n, seed=5)
+    t = torch.from_numpy(keys).cuda()
+    pay = torch.arange(n, dtype=torch.int32, device="cuda")
+    u = keys.view(np.uint64) ^ np.uint64(1 << 63)
+    with mod.Engine("int64", n, payload=True) as e:
+        e.set_stream(torch.cuda.current_stream().cuda_stream)
+        e.set_option(mod.OPT_RADIX_BITS, 8)
+        for first, last in ((0, 16), (0, 14), (2, 8), (1, 16), (0, 5)):      # whole bytes -> 8-bit passes; otherwise the 4-bit chain
+            out = torch.zeros(n + 5, dtype=t.dtype, device="cuda")
+            pout = torch.zeros(n + 5, dtype=torch.int32, device="cuda")
+            e.sort_from_to(t.data_ptr(), n, first, last, out[2:].data_ptr(), pay.data_ptr(), pout[2:].data_ptr())
+            torch.cuda.synchronize()
+            field = (u >> np.uint64(4 * first)) & np.uint64((1 << (4 * (last - first))) - 1) if last - first < 16 else u
+            order = np.argsort(field, kind="stable")
+            got = out.cpu().numpy()
+            assert np.array_equal(got[2:2 + n], keys[order]) and not got[:2].any() and not got[2 + n:].any(), (first, last)
+            assert np.array_equal(pout.cpu().numpy().view(np.uint32)[2:2 + n], order.astype(np.uint32))
+        assert np.array_equal(t.cpu().numpy(), keys)
+
+
+def test_8bit_digits_full_size_2pow28_bit_exact_vs_oracle(mod, oracle):
+    n = 1 << 28
+    keys = oracle.dataset("Random", "uint32", n)
+    with mod.Engine("uint32", n) as e:
+        e.set_option(mod.OPT_RADIX_BITS, 8)
+        e.upload(keys)
+        e.sort()
+        got = e.download()
+    assert np.array_equal(got, oracle.radix_sort(keys))
+
+
 # --------------------------------------------------------------------------- table scan variants
 @pytest.mark.parametrize("dt,payload", [("uint32", False), ("int64", True)])
 @pytest.mark.parametrize("n", [5000, 300001, (1 << 22) + 17, (1 << 24) + 4097])

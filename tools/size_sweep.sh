@@ -4,7 +4,7 @@ OUT=${1:-gpurun_out/size_sweep.jsonl}; shift
 SIZES=${@:-"8 10 12 14 16 18 20 22 24 26 28"}
 : > "$OUT"
 for p in $SIZES; do
-  python bench.py --log2-keys $p --steps $([ $p -le 22 ] && echo 200 || echo 30) --warmup 5 --no-events --no-cpu-baseline 2>/dev/null | tail -1 >> "$OUT"
+  python bench.py $BENCH_ARGS --log2-keys $p --steps $([ $p -le 22 ] && echo 200 || echo 30) --warmup 5 --no-events --no-cpu-baseline 2>/dev/null | tail -1 >> "$OUT"
 done
 python - "$OUT" <<'PY'
 import json, sys
