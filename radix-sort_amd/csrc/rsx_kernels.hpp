@@ -1565,7 +1565,7 @@ __global__ __launch_bounds__(kScan8Threads) void scan8_groups_kernel(uint32_t* _
 {
     constexpr int SLICES = kScan8Threads / kRadix8;
     __shared__ uint32_t slice_tot[SLICES][kRadix8];
-    __shared__ uint32_t wtot[kRadix8 / kWave];
+    __shared__ uint32_t wtot[kScan8Threads / kWave];
     __shared__ uint32_t digit_base[kRadix8];
     const uint32_t tid = threadIdx.x, d = tid & (kRadix8 - 1), q = tid >> 8;
     const uint32_t per = (ngroups + SLICES - 1) / SLICES;
@@ -1583,11 +1583,14 @@ __global__ __launch_bounds__(kScan8Threads) void scan8_groups_kernel(uint32_t* _
         total += v;
         before_slices += (static_cast<uint32_t>(s2) < q) ? v : 0u;
     }
-    if (tid < kRadix8) {
+    {
+        // every thread takes part (the scan has barriers inside); only slice 0 carries the digit totals
         uint32_t all;
-        const uint32_t base = block_exclusive_scan<kRadix8>(total, wtot, all);      // keys with a smaller digit
-        digit_base[d] = base;
-        if (tid == kRadix8 - 1) {
+        const uint32_t base = block_exclusive_scan<kScan8Threads>(tid < kRadix8 ? total : 0u, wtot, all);      // keys with a smaller digit
+        if (tid < kRadix8) {
+            digit_base[d] = base;
+        }
+        if (tid == 0) {
             temp[0] = all;
         }
     }
