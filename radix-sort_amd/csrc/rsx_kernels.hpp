@@ -1454,11 +1454,11 @@ __global__ __launch_bounds__(THREADS) void tile_sort_kernel(const Key* in, Key* 
 // Tables are [tile][256] (a tile's 256 counters are one contiguous 1 KiB row):
 //   histogram8_kernel   counts8[tile][d]   = keys of the tile with digit d
 //   scan8_blocks_kernel table8[tile][d]    = keys with digit d in EARLIER tiles of the tile's group (G tiles); gsum8[group][d] = group total
-//   scan8_groups_kernel gsum8[group][d]    = global slot of the first key of (digit d, group): all smaller digits + earlier groups
-//   reorder8_kernel     slot of a key      = gsum8[group][d] + table8[tile][d] + (its rank inside the tile's run of digit d)
+//   scan8_chunks_kernel gsum8[group][d]    = keys with digit d in earlier groups of the group's chunk; csum8[chunk][d] = chunk total
+//   reorder8_kernel     slot of a key      = (keys with smaller digits) + (digit d in earlier chunks) + gsum8[group][d] + table8[tile][d]
+//                                            + (its rank inside the tile's run of digit d)
 constexpr int kRadix8 = 256;
 constexpr int kScan8Tiles = 64;               // tiles per scan group
-constexpr int kScan8Threads = 1024;           // scan8_groups_kernel: 256 digits x 4 slices of the groups
 
 template <typename Key>
 __device__ __forceinline__ uint32_t digit8_of(Key key, int shift, Key flip)
@@ -1559,48 +1559,38 @@ __global__ __launch_bounds__(kRadix8) void scan8_blocks_kernel(const uint32_t* _
     gsum8[static_cast<uint64_t>(group) * kRadix8 + d] = run;
 }
 
-// ONE workgroup: gsum8[group][d] (group totals) -> global slot of the first key of (digit d, group).  Thread
-// (slice q = tid >> 8, digit d = tid & 255) walks its quarter of the groups.
-__global__ __launch_bounds__(kScan8Threads) void scan8_groups_kernel(uint32_t* __restrict__ gsum8, uint32_t* __restrict__ temp, uint32_t ngroups)
+// Second level: the groups are cut into at most kScan8MaxChunks chunks of `chunk_groups` consecutive groups; one
+// workgroup per chunk turns its groups' totals into exclusive prefixes INSIDE the chunk (thread d walks the rows,
+// eight loads in flight) and leaves the chunk total in csum8[chunk][d].  The third level — at most 16 chunk totals
+// per digit and the digit bases — is small enough for every reorder8 workgroup to redo itself while its keys are
+// on their way, so there is no launch for it.
+constexpr int kScan8MaxChunks = 16;
+
+__global__ __launch_bounds__(kRadix8) void scan8_chunks_kernel(uint32_t* __restrict__ gsum8, uint32_t* __restrict__ csum8, uint32_t ngroups, uint32_t chunk_groups)
 {
-    constexpr int SLICES = kScan8Threads / kRadix8;
-    __shared__ uint32_t slice_tot[SLICES][kRadix8];
-    __shared__ uint32_t wtot[kScan8Threads / kWave];
-    __shared__ uint32_t digit_base[kRadix8];
-    const uint32_t tid = threadIdx.x, d = tid & (kRadix8 - 1), q = tid >> 8;
-    const uint32_t per = (ngroups + SLICES - 1) / SLICES;
-    const uint32_t g0 = q * per, g1 = (g0 + per < ngroups) ? g0 + per : ngroups;
-    uint32_t sum = 0;
-    for (uint32_t g = g0; g < g1; ++g) {
-        sum += gsum8[static_cast<uint64_t>(g) * kRadix8 + d];
-    }
-    slice_tot[q][d] = sum;
-    __syncthreads();
-    uint32_t total = 0, before_slices = 0;
+    const uint32_t d = threadIdx.x, chunk = blockIdx.x;
+    const uint32_t g0 = chunk * chunk_groups;
+    const uint32_t g1 = g0 + chunk_groups < ngroups ? g0 + chunk_groups : ngroups;
+    uint32_t run = 0;
+    uint32_t g = g0;
+    for (; g + 8 <= g1; g += 8) {
+        uint32_t c[8];
 #pragma unroll
-    for (int s2 = 0; s2 < SLICES; ++s2) {
-        const uint32_t v = slice_tot[s2][d];
-        total += v;
-        before_slices += (static_cast<uint32_t>(s2) < q) ? v : 0u;
-    }
-    {
-        // every thread takes part (the scan has barriers inside); only slice 0 carries the digit totals
-        uint32_t all;
-        const uint32_t base = block_exclusive_scan<kScan8Threads>(tid < kRadix8 ? total : 0u, wtot, all);      // keys with a smaller digit
-        if (tid < kRadix8) {
-            digit_base[d] = base;
+        for (int u = 0; u < 8; ++u) {
+            c[u] = gsum8[static_cast<uint64_t>(g + u) * kRadix8 + d];
         }
-        if (tid == 0) {
-            temp[0] = all;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            gsum8[static_cast<uint64_t>(g + u) * kRadix8 + d] = run;
+            run += c[u];
         }
     }
-    __syncthreads();
-    uint32_t run = digit_base[d] + before_slices;
-    for (uint32_t g = g0; g < g1; ++g) {
+    for (; g < g1; ++g) {
         const uint32_t c = gsum8[static_cast<uint64_t>(g) * kRadix8 + d];
         gsum8[static_cast<uint64_t>(g) * kRadix8 + d] = run;
         run += c;
     }
+    csum8[static_cast<uint64_t>(chunk) * kRadix8 + d] = run;
 }
 
 template <typename Key, int THREADS, int KPT>
@@ -1619,8 +1609,8 @@ struct Reorder8Layout {
 template <typename Key, int THREADS, int KPT, bool PAYLOAD>
 __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREADS, KPT>::MIN_WAVES > 4 ? 4 : Reorder8Layout<Key, THREADS, KPT>::MIN_WAVES))) void reorder8_kernel(
     const Key* __restrict__ in, Key* __restrict__ out, const uint32_t* __restrict__ pin, uint32_t* __restrict__ pout,
-    const uint32_t* __restrict__ counts8, const uint32_t* __restrict__ table8, const uint32_t* __restrict__ gsum8, uint64_t n, uint32_t ntiles,
-    uint32_t tiles_per_xcd, int remap, int shift, Key flip)
+    const uint32_t* __restrict__ counts8, const uint32_t* __restrict__ table8, const uint32_t* __restrict__ gsum8, const uint32_t* __restrict__ csum8,
+    uint32_t nchunks, uint32_t chunk_groups, uint32_t* __restrict__ temp, uint64_t n, uint32_t ntiles, uint32_t tiles_per_xcd, int remap, int shift, Key flip)
 {
     using L = Reorder8Layout<Key, THREADS, KPT>;
     constexpr int TILE = THREADS * KPT;
@@ -1646,7 +1636,17 @@ __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREAD
 
     // this thread's digit of the tile's table row (latency hides under the key loads)
     const uint32_t my_count = counts8[static_cast<uint64_t>(tile) * kRadix8 + tid];
-    const uint32_t my_first = table8[static_cast<uint64_t>(tile) * kRadix8 + tid] + gsum8[static_cast<uint64_t>(tile / kScan8Tiles) * kRadix8 + tid];
+    const uint32_t group = tile / kScan8Tiles;
+    uint32_t my_first = table8[static_cast<uint64_t>(tile) * kRadix8 + tid] + gsum8[static_cast<uint64_t>(group) * kRadix8 + tid];
+    uint32_t digit_total = 0;                 // all keys with digit `tid`; my_first gathers those in earlier chunks
+    {
+        const uint32_t my_chunk = group / chunk_groups;
+        for (uint32_t w = 0; w < nchunks; ++w) {
+            const uint32_t v = csum8[static_cast<uint64_t>(w) * kRadix8 + tid];
+            digit_total += v;
+            my_first += (w < my_chunk) ? v : 0u;
+        }
+    }
 
     Key k[KPT];
     uint32_t pl[PAYLOAD ? KPT : 1];
@@ -1679,11 +1679,16 @@ __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREAD
             }
         }
     }
-    // local first slot of every digit = exclusive scan of the tile's 256 counts; gb = global first - local first
+    // local first slot of every digit = exclusive scan of the tile's 256 counts; keys with a smaller digit = exclusive
+    // scan of the digit totals; gb = global first - local first
     {
         uint32_t all;
         const uint32_t local_first = block_exclusive_scan<THREADS>(my_count, wtot, all);
-        gb[tid] = my_first - local_first;
+        const uint32_t smaller = block_exclusive_scan<THREADS>(digit_total, wtot, all);
+        gb[tid] = my_first + smaller - local_first;
+        if (tile == 0 && tid == 0) {
+            temp[0] = all;                    // grand total, as the 4-bit scan leaves it
+        }
     }
     u32_alias* cnt32 = reinterpret_cast<u32_alias*>(cnt);
     const u16_alias* cnt16 = reinterpret_cast<const u16_alias*>(cnt);
