@@ -1640,11 +1640,17 @@ __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREAD
     uint32_t my_first = table8[static_cast<uint64_t>(tile) * kRadix8 + tid] + gsum8[static_cast<uint64_t>(group) * kRadix8 + tid];
     uint32_t digit_total = 0;                 // all keys with digit `tid`; my_first gathers those in earlier chunks
     {
+        // all loads in flight at once (a loop with a run-time trip count would expose one L2 round trip per chunk)
         const uint32_t my_chunk = group / chunk_groups;
-        for (uint32_t w = 0; w < nchunks; ++w) {
-            const uint32_t v = csum8[static_cast<uint64_t>(w) * kRadix8 + tid];
-            digit_total += v;
-            my_first += (w < my_chunk) ? v : 0u;
+        uint32_t cs[kScan8MaxChunks];
+#pragma unroll
+        for (int w = 0; w < kScan8MaxChunks; ++w) {
+            cs[w] = static_cast<uint32_t>(w) < nchunks ? csum8[w * kRadix8 + tid] : 0u;
+        }
+#pragma unroll
+        for (int w = 0; w < kScan8MaxChunks; ++w) {
+            digit_total += cs[w];
+            my_first += (static_cast<uint32_t>(w) < my_chunk) ? cs[w] : 0u;
         }
     }
 
