@@ -174,6 +174,7 @@ struct rsx_engine {
     uint32_t* table8 = nullptr;                 //   group-local exclusive prefixes [tile][256]
     uint32_t* gsum8 = nullptr;                  //   per scan group: totals, then prefixes inside the group's chunk [group][256]
     uint32_t* csum8 = nullptr;                  //   per chunk of groups: totals [chunk <= 16][256]
+    uint32_t* cbase8 = nullptr;                 //   per chunk: smaller digits + this digit in earlier chunks [chunk][256]
     int tile_sort = 1;          // rsx_sort: inputs of at most one tile are sorted by ONE workgroup in ONE launch, all passes in LDS (env RSX_TILE_SORT)
     int fold_paste = 0;         // reorder adds globsum itself (no paste launch): measured 3 % slower, off; env RSX_FOLD_PASTE
     int scan_zeroes = 1;
@@ -551,6 +552,7 @@ int sort8_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext
         RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->table8), rows), RSX_INITIALIZATION_FAILED);
         RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->gsum8), groups), RSX_INITIALIZATION_FAILED);
         RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->csum8), rsx::kScan8MaxChunks * rsx::kRadix8 * 4), RSX_INITIALIZATION_FAILED);
+        RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->cbase8), rsx::kScan8MaxChunks * rsx::kRadix8 * 4), RSX_INITIALIZATION_FAILED);
         RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L::BYTES)), RSX_INITIALIZATION_FAILED);
         RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, true>),
@@ -579,17 +581,18 @@ int sort8_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext
         {
             Bracket b(e, PH_SCAN);
             hipLaunchKernelGGL(rsx::scan8_chunks_kernel, dim3(nchunks), dim3(rsx::kRadix8), 0, e->stream, e->gsum8, e->csum8, ngroups, chunk_groups);
+            hipLaunchKernelGGL(rsx::scan8_top_kernel, dim3(1), dim3(rsx::kRadix8), 0, e->stream, e->csum8, e->cbase8, e->temp, nchunks);
         }
         {
             Bracket b(e, PH_REORDER);
             if (e->has_payload) {
                 hipLaunchKernelGGL((rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, true>), dim3(g.blocks), dim3(kTileThreads), L::BYTES, e->stream,
-                                   static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->counts8, e->table8, e->gsum8, e->csum8, nchunks, chunk_groups,
-                                   e->temp, count, g.ntiles, g.tiles_per_xcd, e->xcd_remap, shift, flip);
+                                   static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->counts8, e->table8, e->gsum8, e->cbase8, chunk_groups,
+                                   count, g.ntiles, g.tiles_per_xcd, e->xcd_remap, shift, flip);
             } else {
                 hipLaunchKernelGGL((rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, false>), dim3(g.blocks), dim3(kTileThreads), L::BYTES, e->stream,
-                                   static_cast<const Key*>(in), static_cast<Key*>(out), nullptr, nullptr, e->counts8, e->table8, e->gsum8, e->csum8, nchunks, chunk_groups,
-                                   e->temp, count, g.ntiles, g.tiles_per_xcd, e->xcd_remap, shift, flip);
+                                   static_cast<const Key*>(in), static_cast<Key*>(out), nullptr, nullptr, e->counts8, e->table8, e->gsum8, e->cbase8, chunk_groups,
+                                   count, g.ntiles, g.tiles_per_xcd, e->xcd_remap, shift, flip);
             }
         }
         RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
@@ -984,6 +987,7 @@ int rsx_destroy(rsx_engine* e)
     if (e->table8 && hipFree(e->table8) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->gsum8 && hipFree(e->gsum8) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->csum8 && hipFree(e->csum8) != hipSuccess) status = RSX_CLEANUP_FAILED;
+    if (e->cbase8 && hipFree(e->cbase8) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->scan_timeout && hipFree(e->scan_timeout) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->scan_timeout_host && hipHostFree(e->scan_timeout_host) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->starts_dev && hipFree(e->starts_dev) != hipSuccess) status = RSX_CLEANUP_FAILED;

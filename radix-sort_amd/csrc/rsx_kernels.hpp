@@ -1561,10 +1561,35 @@ __global__ __launch_bounds__(kRadix8) void scan8_blocks_kernel(const uint32_t* _
 
 // Second level: the groups are cut into at most kScan8MaxChunks chunks of `chunk_groups` consecutive groups; one
 // workgroup per chunk turns its groups' totals into exclusive prefixes INSIDE the chunk (thread d walks the rows,
-// eight loads in flight) and leaves the chunk total in csum8[chunk][d].  The third level — at most 16 chunk totals
-// per digit and the digit bases — is small enough for every reorder8 workgroup to redo itself while its keys are
-// on their way, so there is no launch for it.
+// eight loads in flight) and leaves the chunk total in csum8[chunk][d].  Third level (scan8_top_kernel, one
+// workgroup, a few microseconds): cbase8[chunk][d] = keys with a smaller digit + keys with digit d in earlier chunks.
 constexpr int kScan8MaxChunks = 16;
+
+__global__ __launch_bounds__(kRadix8) void scan8_top_kernel(const uint32_t* __restrict__ csum8, uint32_t* __restrict__ cbase8, uint32_t* __restrict__ temp,
+                                                            uint32_t nchunks)
+{
+    __shared__ uint32_t wtot[kRadix8 / kWave];
+    const uint32_t d = threadIdx.x;
+    uint32_t cs[kScan8MaxChunks];
+    uint32_t total = 0;
+#pragma unroll
+    for (int w = 0; w < kScan8MaxChunks; ++w) {
+        cs[w] = static_cast<uint32_t>(w) < nchunks ? csum8[w * kRadix8 + d] : 0u;
+        total += cs[w];
+    }
+    uint32_t all;
+    uint32_t run = block_exclusive_scan<kRadix8>(total, wtot, all);
+#pragma unroll
+    for (int w = 0; w < kScan8MaxChunks; ++w) {
+        if (static_cast<uint32_t>(w) < nchunks) {
+            cbase8[w * kRadix8 + d] = run;
+        }
+        run += cs[w];
+    }
+    if (d == 0) {
+        temp[0] = all;                        // grand total, as the 4-bit scan leaves it
+    }
+}
 
 __global__ __launch_bounds__(kRadix8) void scan8_chunks_kernel(uint32_t* __restrict__ gsum8, uint32_t* __restrict__ csum8, uint32_t ngroups, uint32_t chunk_groups)
 {
@@ -1609,8 +1634,8 @@ struct Reorder8Layout {
 template <typename Key, int THREADS, int KPT, bool PAYLOAD>
 __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREADS, KPT>::MIN_WAVES > 4 ? 4 : Reorder8Layout<Key, THREADS, KPT>::MIN_WAVES))) void reorder8_kernel(
     const Key* __restrict__ in, Key* __restrict__ out, const uint32_t* __restrict__ pin, uint32_t* __restrict__ pout,
-    const uint32_t* __restrict__ counts8, const uint32_t* __restrict__ table8, const uint32_t* __restrict__ gsum8, const uint32_t* __restrict__ csum8,
-    uint32_t nchunks, uint32_t chunk_groups, uint32_t* __restrict__ temp, uint64_t n, uint32_t ntiles, uint32_t tiles_per_xcd, int remap, int shift, Key flip)
+    const uint32_t* __restrict__ counts8, const uint32_t* __restrict__ table8, const uint32_t* __restrict__ gsum8, const uint32_t* __restrict__ cbase8,
+    uint32_t chunk_groups, uint64_t n, uint32_t ntiles, uint32_t tiles_per_xcd, int remap, int shift, Key flip)
 {
     using L = Reorder8Layout<Key, THREADS, KPT>;
     constexpr int TILE = THREADS * KPT;
@@ -1638,21 +1663,7 @@ __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREAD
     const uint32_t my_count = counts8[static_cast<uint64_t>(tile) * kRadix8 + tid];
     const uint32_t group = tile / kScan8Tiles;
     uint32_t my_first = table8[static_cast<uint64_t>(tile) * kRadix8 + tid] + gsum8[static_cast<uint64_t>(group) * kRadix8 + tid];
-    uint32_t digit_total = 0;                 // all keys with digit `tid`; my_first gathers those in earlier chunks
-    {
-        // all loads in flight at once (a loop with a run-time trip count would expose one L2 round trip per chunk)
-        const uint32_t my_chunk = group / chunk_groups;
-        uint32_t cs[kScan8MaxChunks];
-#pragma unroll
-        for (int w = 0; w < kScan8MaxChunks; ++w) {
-            cs[w] = static_cast<uint32_t>(w) < nchunks ? csum8[w * kRadix8 + tid] : 0u;
-        }
-#pragma unroll
-        for (int w = 0; w < kScan8MaxChunks; ++w) {
-            digit_total += cs[w];
-            my_first += (static_cast<uint32_t>(w) < my_chunk) ? cs[w] : 0u;
-        }
-    }
+    my_first += cbase8[static_cast<uint64_t>(group / chunk_groups) * kRadix8 + tid];      // smaller digits + this digit in earlier chunks
 
     Key k[KPT];
     uint32_t pl[PAYLOAD ? KPT : 1];
@@ -1685,16 +1696,11 @@ __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREAD
             }
         }
     }
-    // local first slot of every digit = exclusive scan of the tile's 256 counts; keys with a smaller digit = exclusive
-    // scan of the digit totals; gb = global first - local first
+    // local first slot of every digit = exclusive scan of the tile's 256 counts; gb = global first - local first
     {
         uint32_t all;
         const uint32_t local_first = block_exclusive_scan<THREADS>(my_count, wtot, all);
-        const uint32_t smaller = block_exclusive_scan<THREADS>(digit_total, wtot, all);
-        gb[tid] = my_first + smaller - local_first;
-        if (tile == 0 && tid == 0) {
-            temp[0] = all;                    // grand total, as the 4-bit scan leaves it
-        }
+        gb[tid] = my_first - local_first;
     }
     u32_alias* cnt32 = reinterpret_cast<u32_alias*>(cnt);
     const u16_alias* cnt16 = reinterpret_cast<const u16_alias*>(cnt);
