@@ -580,8 +580,12 @@ int sort8_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext
         }
         {
             Bracket b(e, PH_SCAN);
-            hipLaunchKernelGGL(rsx::scan8_chunks_kernel, dim3(nchunks), dim3(rsx::kRadix8), 0, e->stream, e->gsum8, e->csum8, ngroups, chunk_groups);
-            hipLaunchKernelGGL(rsx::scan8_top_kernel, dim3(1), dim3(rsx::kRadix8), 0, e->stream, e->csum8, e->cbase8, e->temp, nchunks);
+            if (nchunks == 1) {
+                hipLaunchKernelGGL(rsx::scan8_chunks_kernel<true>, dim3(1), dim3(rsx::kRadix8), 0, e->stream, e->gsum8, e->csum8, ngroups, chunk_groups, e->cbase8, e->temp);
+            } else {
+                hipLaunchKernelGGL(rsx::scan8_chunks_kernel<false>, dim3(nchunks), dim3(rsx::kRadix8), 0, e->stream, e->gsum8, e->csum8, ngroups, chunk_groups, e->cbase8, e->temp);
+                hipLaunchKernelGGL(rsx::scan8_top_kernel, dim3(1), dim3(rsx::kRadix8), 0, e->stream, e->csum8, e->cbase8, e->temp, nchunks);
+            }
         }
         {
             Bracket b(e, PH_REORDER);

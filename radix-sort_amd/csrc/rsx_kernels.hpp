@@ -1591,8 +1591,13 @@ __global__ __launch_bounds__(kRadix8) void scan8_top_kernel(const uint32_t* __re
     }
 }
 
-__global__ __launch_bounds__(kRadix8) void scan8_chunks_kernel(uint32_t* __restrict__ gsum8, uint32_t* __restrict__ csum8, uint32_t ngroups, uint32_t chunk_groups)
+// ONLY_CHUNK (a table of one chunk, i.e. up to 2^24 keys): the workgroup is also the top level — the digit bases
+// go straight to cbase8[0][d] and the grand total to temp[0]; no scan8_top_kernel launch.
+template <bool ONLY_CHUNK>
+__global__ __launch_bounds__(kRadix8) void scan8_chunks_kernel(uint32_t* __restrict__ gsum8, uint32_t* __restrict__ csum8, uint32_t ngroups, uint32_t chunk_groups,
+                                                               uint32_t* __restrict__ cbase8, uint32_t* __restrict__ temp)
 {
+    __shared__ uint32_t wtot[kRadix8 / kWave];
     const uint32_t d = threadIdx.x, chunk = blockIdx.x;
     const uint32_t g0 = chunk * chunk_groups;
     const uint32_t g1 = g0 + chunk_groups < ngroups ? g0 + chunk_groups : ngroups;
@@ -1616,6 +1621,13 @@ __global__ __launch_bounds__(kRadix8) void scan8_chunks_kernel(uint32_t* __restr
         run += c;
     }
     csum8[static_cast<uint64_t>(chunk) * kRadix8 + d] = run;
+    if constexpr (ONLY_CHUNK) {
+        uint32_t all;
+        cbase8[d] = block_exclusive_scan<kRadix8>(run, wtot, all);
+        if (d == 0) {
+            temp[0] = all;
+        }
+    }
 }
 
 template <typename Key, int THREADS, int KPT>
