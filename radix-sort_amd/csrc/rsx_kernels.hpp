@@ -1654,6 +1654,7 @@ __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREAD
     constexpr int KD = L::KD;
     constexpr int VEC = KeyVec<Key>::N;
     constexpr int NV = KPT / VEC;
+    constexpr uint32_t CNT_ROW_BYTES = THREADS * 4;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* xbuf = smem;
     uint32_t* cnt = smem + L::XBUF_DW;
@@ -1664,18 +1665,24 @@ __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREAD
     if (tile >= ntiles) {
         return;
     }
+    if (!lds_base_is_zero(smem)) {
+        __builtin_trap();           // lds_store_at addresses the image from LDS address 0
+    }
     const uint64_t base = static_cast<uint64_t>(tile) * TILE;
     const uint64_t left = n - base;
     const uint32_t valid = left < static_cast<uint64_t>(TILE) ? static_cast<uint32_t>(left) : static_cast<uint32_t>(TILE);
     const bool full = (valid == TILE);
-    const Key pad_key = static_cast<Key>(~flip);          // digit 255, behind every real key of the tile
-    auto image_dw = [](uint32_t s) { return s * KD + ((s >> 4) << 2); };
+    // Inside the kernel keys are held with the sign bit flipped (k ^ flip: unsigned order = numeric order), so the
+    // digits are plain bit fields; the flip is undone on the way out.  Unsigned types skip both (flip == 0, uniform).
+    const Key pad_key = static_cast<Key>(~Key{0});        // digit 255, behind every real key of the tile
+    const bool hi = sizeof(Key) == 8 && shift >= 32;      // the byte never straddles the halves of a 64-bit key
+    const uint32_t sh = static_cast<uint32_t>(shift) & 31u;
 
     // this thread's digit of the tile's table row (latency hides under the key loads)
     const uint32_t my_count = counts8[static_cast<uint64_t>(tile) * kRadix8 + tid];
     const uint32_t group = tile / kScan8Tiles;
-    uint32_t my_first = table8[static_cast<uint64_t>(tile) * kRadix8 + tid] + gsum8[static_cast<uint64_t>(group) * kRadix8 + tid];
-    my_first += cbase8[static_cast<uint64_t>(group / chunk_groups) * kRadix8 + tid];      // smaller digits + this digit in earlier chunks
+    const uint32_t my_first = table8[static_cast<uint64_t>(tile) * kRadix8 + tid] + gsum8[static_cast<uint64_t>(group) * kRadix8 + tid] +
+                              cbase8[static_cast<uint64_t>(group / chunk_groups) * kRadix8 + tid];      // smaller digits + this digit in earlier chunks
 
     Key k[KPT];
     uint32_t pl[PAYLOAD ? KPT : 1];
@@ -1698,11 +1705,17 @@ __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREAD
                 pl[q * 4 + 3] = x.v[3];
             }
         }
+        if (flip != Key{0}) {
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                k[i] ^= flip;
+            }
+        }
     } else {
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
             const uint32_t li = tid * KPT + i;
-            k[i] = li < valid ? in[base + li] : pad_key;
+            k[i] = li < valid ? static_cast<Key>(in[base + li] ^ flip) : pad_key;
             if constexpr (PAYLOAD) {
                 pl[i] = li < valid ? pin[base + li] : 0u;
             }
@@ -1715,28 +1728,36 @@ __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREAD
         gb[tid] = my_first - local_first;
     }
     u32_alias* cnt32 = reinterpret_cast<u32_alias*>(cnt);
-    const u16_alias* cnt16 = reinterpret_cast<const u16_alias*>(cnt);
+    unsigned char* cbytes = reinterpret_cast<unsigned char*>(cnt);
+    // image: slot s at dword s*KD + 4*(s/16) (rows of KPT keys + 16 bytes); slot i = r*THREADS + tid -> per-thread base + r * OUT_STRIDE
+    constexpr uint32_t OUT_STRIDE_DW = THREADS * KD + (THREADS / 16) * 4;
+    const uint32_t out_base_dw = tid * KD + ((tid >> 4) << 2);
 
 #pragma unroll 1
     for (int round = 0; round < 2; ++round) {
-        const int rshift = shift + round * kRadixBits;
-        uint32_t slot[KPT], dg[KPT];
-        uint64_t seen = 0;
+        const uint32_t rsh = sh + static_cast<uint32_t>(round) * kRadixBits;      // sh is a multiple of 8: rsh + 4 <= 32
+        uint32_t slot[KPT];
+        {
+            uint64_t seen = 0;
+            uint32_t d_last = 0;
 #pragma unroll
-        for (int i = 0; i < KPT; ++i) {
-            dg[i] = digit_of(k[i], rshift, flip, static_cast<uint32_t>(kRadix - 1));
-            const uint32_t sh4 = dg[i] << 2;
-            slot[i] = static_cast<uint32_t>(seen >> sh4) & 15u;
-            if (i + 1 < KPT) {
-                seen += 1ull << sh4;
+            for (int i = 0; i < KPT; ++i) {
+                const uint32_t d = __builtin_amdgcn_ubfe(field_word(k[i], hi), rsh, 4u);
+                const uint32_t sh4 = d << 2;
+                slot[i] = static_cast<uint32_t>(seen >> sh4) & 15u;
+                if (i + 1 < KPT) {
+                    seen += 1ull << sh4;
+                } else {
+                    d_last = d;
+                }
             }
-        }
-        const uint32_t seen_lo = static_cast<uint32_t>(seen), seen_hi = static_cast<uint32_t>(seen >> 32);
+            const uint32_t seen_lo = static_cast<uint32_t>(seen), seen_hi = static_cast<uint32_t>(seen >> 32);
 #pragma unroll
-        for (int l = 0; l < 8; ++l) {
-            cnt32[l * THREADS + tid] = __builtin_amdgcn_ubfe(seen_lo, 4u * l, 4u) | (__builtin_amdgcn_ubfe(seen_hi, 4u * l, 4u) << 16);
+            for (int l = 0; l < 8; ++l) {
+                cnt32[l * THREADS + tid] = __builtin_amdgcn_ubfe(seen_lo, 4u * l, 4u) | (__builtin_amdgcn_ubfe(seen_hi, 4u * l, 4u) << 16);
+            }
+            atomicAdd(cnt + (d_last & 7u) * THREADS + tid, 1u << ((d_last >> 3) * 16u));
         }
-        atomicAdd(cnt + (dg[KPT - 1] & 7u) * THREADS + tid, 1u << ((dg[KPT - 1] >> 3) * 16u));
         __syncthreads();
         {
             U32x4 a = *reinterpret_cast<const U32x4*>(cnt + tid * 8);
@@ -1762,7 +1783,10 @@ __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREAD
             uint32_t first_of_digit[KPT];
 #pragma unroll
             for (int i = 0; i < KPT; ++i) {
-                first_of_digit[i] = cnt16[(((dg[i] & 7u) * THREADS + tid) << 1) + (dg[i] >> 3)];
+                const uint32_t w = field_word(k[i], hi);
+                const uint32_t l3 = __builtin_amdgcn_ubfe(w, rsh, 3u);
+                const uint32_t h = __builtin_amdgcn_ubfe(w, rsh + 3u, 1u);
+                first_of_digit[i] = *reinterpret_cast<const u16_alias*>(cbytes + (l3 * CNT_ROW_BYTES + tid * 4u) + h * 2u);
             }
 #pragma unroll
             for (int i = 0; i < KPT; ++i) {
@@ -1770,7 +1794,12 @@ __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREAD
             }
 #pragma unroll
             for (int i = 0; i < KPT; ++i) {
-                *reinterpret_cast<Key*>(xbuf + image_dw(slot[i])) = k[i];
+                // byte offset of slot s: (s*KD + 4*(s>>4)) * 4
+                if constexpr (KD == 1) {
+                    lds_store_at<Key>(add_lshl<2>(slot[i], (slot[i] >> 2) & ~3u), k[i]);
+                } else {
+                    lds_store_at<Key>(add_lshl<2>(slot[i] << 1, (slot[i] >> 2) & ~3u), k[i]);
+                }
             }
         }
         __syncthreads();
@@ -1785,16 +1814,37 @@ __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREAD
             }
         } else {
             // leave as runs: slot i = r*THREADS + tid, its global slot = gb[digit] + i
+            Key okey[KPT];
 #pragma unroll
             for (int r = 0; r < KPT; ++r) {
-                const uint32_t i = static_cast<uint32_t>(r) * THREADS + tid;
-                const Key key = *reinterpret_cast<const Key*>(xbuf + image_dw(i));
-                const uint32_t g = gb[digit8_of(key, shift, flip)] + i;
-                if (full || i < valid) {
-                    out[g] = key;
+                okey[r] = *reinterpret_cast<const Key*>(xbuf + out_base_dw + static_cast<uint32_t>(r) * OUT_STRIDE_DW);
+            }
+            uint32_t g[KPT];
+#pragma unroll
+            for (int r = 0; r < KPT; ++r) {
+                g[r] = gb[__builtin_amdgcn_ubfe(field_word(okey[r], hi), sh, 8u)];
+            }
+#pragma unroll
+            for (int r = 0; r < KPT; ++r) {
+                g[r] += tid + static_cast<uint32_t>(r) * THREADS;
+            }
+            if (full) {
+#pragma unroll
+                for (int r = 0; r < KPT; ++r) {
+                    out[g[r]] = static_cast<Key>(okey[r] ^ flip);
                 }
-                if constexpr (PAYLOAD) {
-                    dg[r] = g;                    // the payload of slot i follows to the same place
+            } else {
+#pragma unroll
+                for (int r = 0; r < KPT; ++r) {
+                    if (static_cast<uint32_t>(r) * THREADS + tid < valid) {
+                        out[g[r]] = static_cast<Key>(okey[r] ^ flip);
+                    }
+                }
+            }
+            if constexpr (PAYLOAD) {
+#pragma unroll
+                for (int r = 0; r < KPT; ++r) {
+                    k[r] = static_cast<Key>(g[r]);          // keys are gone; keep each slot's destination for its payload
                 }
             }
         }
@@ -1802,7 +1852,7 @@ __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREAD
             __syncthreads();           // every thread has taken its keys: the image carries the payload now
 #pragma unroll
             for (int i = 0; i < KPT; ++i) {
-                xbuf[slot[i] + ((slot[i] >> 4) << 2)] = pl[i];
+                lds_store_at<uint32_t>(add_lshl<2>(slot[i], (slot[i] >> 2) & ~3u), pl[i]);
             }
             __syncthreads();
             if (round == 0) {
@@ -1815,11 +1865,11 @@ __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREAD
                     pl[q * 4 + 3] = x.v[3];
                 }
             } else {
+                const uint32_t pbase = tid + ((tid >> 4) << 2);
 #pragma unroll
                 for (int r = 0; r < KPT; ++r) {
-                    const uint32_t i = static_cast<uint32_t>(r) * THREADS + tid;
-                    if (full || i < valid) {
-                        pout[dg[r]] = xbuf[i + ((i >> 4) << 2)];
+                    if (full || static_cast<uint32_t>(r) * THREADS + tid < valid) {
+                        pout[static_cast<uint32_t>(k[r])] = xbuf[pbase + static_cast<uint32_t>(r) * (THREADS + (THREADS / 16) * 4)];
                     }
                 }
             }
