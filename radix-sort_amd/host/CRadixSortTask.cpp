@@ -87,6 +87,7 @@ bool CRadixSortTask<T>::InitResources(hipc::Device Device, hipc::Context Context
     const HostSpans<T> spans = MakeHostSpans(hb);
     mRadixSortGPU.enablePermutation(mOptions.with_permutation);
     mRadixSortGPU.setStepwise(mOptions.stepwise);
+    mRadixSortGPU.setRadixBits(mOptions.radix_bits);
     mRadixSortGPU.enablePinnedTransfers(mOptions.pinned);
     const auto status = mRadixSortGPU.initialize(Device, Context, mNumberKeys, spans);
     if (status != OperationStatus::OK) {

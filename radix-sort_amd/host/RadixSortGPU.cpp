@@ -54,7 +54,11 @@ OperationStatus RadixSortGPU<DataType>::initialize(hipc::Device Device, hipc::Co
     }
     rsx_resize(mEngine, mNumberKeysRounded);
     rsx_set_option(mEngine, RSX_OPT_PROFILE, 1);   // RuntimesGPU is always filled, as in the reference
-    rsx_set_option(mEngine, RSX_OPT_REF_DIAGNOSTICS, 1);   // m_hHistograms / m_hGlobsum in the reference's geometry
+    rsx_set_option(mEngine, RSX_OPT_REF_DIAGNOSTICS, mRadixBits == 4 ? 1 : 0);   // m_hHistograms / m_hGlobsum in the reference's geometry (4-bit passes only)
+    if (mRadixBits != 4 && rsx_set_option(mEngine, RSX_OPT_RADIX_BITS, mRadixBits) != RSX_OK) {
+        release();
+        return S::INITIALIZATION_FAILED;
+    }
     mPinned = false;
     if (mPinHost) {
         const std::uint64_t keyBytes = static_cast<std::uint64_t>(mNumberKeysRounded) * sizeof(DataType);

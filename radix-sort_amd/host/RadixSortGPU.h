@@ -59,6 +59,9 @@ public:
     /// Call before initialize().
     void enablePermutation(bool on) noexcept { mWithPermutation = on; }
     void setStepwise(bool on) noexcept { mStepwise = on; }
+    /// Digit width of calculate()'s fused pass loop: 4 (the reference's _NUM_BITS_PER_RADIX, src/Parameters.h:25) or 8 (half the
+    /// passes; same result).  The stepwise launchers and the diagnostic read-backs stay those of 4-bit passes.  Call before initialize().
+    void setRadixBits(int bits) noexcept { mRadixBits = bits; }
     /// Page-lock the key / result (and permutation) spans for the engine's lifetime so that
     /// uploadData / downloadData DMA directly (the CL_MEM_USE_HOST_PTR idea the reference notes
     /// at src/ComputeDeviceData.cpp:26).  Call before initialize().
@@ -97,6 +100,7 @@ private:
     void* mBoundStream{nullptr};
     bool mWithPermutation{false};
     bool mStepwise{false};
+    int mRadixBits{4};
     bool mPinHost{false};
     bool mPinned{false};
     std::vector<void*> mExtraPinned{};

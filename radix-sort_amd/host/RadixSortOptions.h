@@ -26,6 +26,7 @@ struct RadixSortOptions {
     bool pinned{false};             ///< --pinned: page-lock the host key/result buffers for the transfers
     bool overlap{false};            ///< --overlap: the timed loop keeps two sorts in flight (upload / sort / download on three streams); implies --pinned
     bool zero_copy{false};          ///< --zero-copy: the timed loop sorts straight out of / into mapped host memory; implies --pinned
+    int radix_bits{4};              ///< --radix-bits 4|8: digit width of the fused sort (the reference's _NUM_BITS_PER_RADIX is a compile-time 4, src/Parameters.h:25)
 
     explicit RadixSortOptions(const std::vector<std::string>& args = {})
         : num_elements(AlgorithmParameters<float>::_NUM_MAX_INPUT_ELEMS)   // default 2^25 (src/RadixSortOptions.h:18)
@@ -52,6 +53,12 @@ struct RadixSortOptions {
             if (*it == "--num-elements") {
                 if (++it == args.end()) throw std::invalid_argument("--num-elements needs a value");
                 num_elements = static_cast<std::size_t>(std::stoull(*it));
+                continue;
+            }
+            if (*it == "--radix-bits") {
+                if (++it == args.end()) throw std::invalid_argument("--radix-bits needs a value");
+                radix_bits = std::stoi(*it);
+                if (radix_bits != 4 && radix_bits != 8) throw std::invalid_argument("--radix-bits must be 4 or 8");
                 continue;
             }
             for (const Switch& sw : kSwitches) {

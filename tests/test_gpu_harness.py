@@ -104,3 +104,10 @@ def test_pipeline_submit_through_the_binding():
             assert np.array_equal(o, np.sort(k)) and np.array_equal(po, np.argsort(k, kind="stable").astype(np.uint32))
         for a in ins + outs + pouts + [perm]:
             e.unpin_host(a)
+
+
+def test_harness_with_8bit_digits():
+    """--radix-bits 8 through the host mirror: the 4x5 matrix validates against std::sort and RadixSortCPU as with 4-bit digits."""
+    proc = _run([os.path.join(BIN, "rsx_tests"), "--num-elements", str((1 << 18) + 3), "--radix-bits", "8", "--with-permutation", "--perf-csv-to-stdout"])
+    assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-2000:]
+    assert "20/20 task runs validated" in proc.stdout and "FAILED" not in proc.stdout
