@@ -42,7 +42,7 @@ def main():
     except (OSError, ValueError):
         doc = {}
     # the graded kernel = the reorder variant launched most often (the fused look-ahead one in rsx_sort)
-    cands = [v for k, v in kernels.items() if "reorder_kernel" in k]
+    cands = [v for k, v in kernels.items() if "reorder_kernel" in k or "reorder8_kernel" in k]
     reorder = max(cands, key=lambda v: v["launches_sampled"][0]) if cands else None
     doc[workload] = {
         "correction": "FETCH_SIZE x2 (gfx950 wide coalesced reads), KiB -> bytes, WRITE_SIZE exact",
