@@ -70,7 +70,7 @@ typedef enum rsx_option {
     RSX_OPT_TILE_SORT = 8,    /* 1 (default): inside rsx_sort, inputs of at most one tile (4096 keys) are sorted by ONE workgroup in
                                  ONE launch, every pass inside LDS; buffers, table and group sums end up as the pass chain
                                  leaves them.  Not taken while RSX_OPT_PROFILE is 1 (per-launch timings of the steps). */
-    RSX_OPT_FUSED_SCAN = 9,   /* 1 (default): inside rsx_sort, tables of up to 1024 scan groups (2^30 keys) are scanned and pasted in
+    RSX_OPT_FUSED_SCAN = 9,   /* 1 (default): inside rsx_sort, tables of up to 512 scan groups (2^29 keys) are scanned and pasted in
                                  ONE launch whose workgroups hand their group sums to each other through tagged 8-byte
                                  granules; 0: scan #1, then scan #2 + paste (two launches).  Same table either way. */
     RSX_OPT_RADIX_BITS = 10,  /* digit width of the rsx_sort chain: 4 (default, the reference's _NUM_BITS_PER_RADIX, src/Parameters.h:25) or 8.

@@ -463,7 +463,7 @@ __global__ __launch_bounds__(kScanTiles) void paste_scan_kernel(uint32_t* __rest
 // the table's second read and write, and the 32 wave scans of the paste.  `epoch` is the engine's launch
 // count (never 0).  A poll that runs out sets *timeout and lets the workgroup finish with garbage rather
 // than hang the GPU (rsx_sync / rsx_download report it).
-constexpr int kFusedScanMaxGroups = 1024;     // 2^30 keys; 256-thread workgroups, <= 4 per CU: all resident
+constexpr int kFusedScanMaxGroups = 512;      // 2^29 keys; 256-thread workgroups, <= 2 per CU: all resident with room to spare (its registers allow 4)
 typedef __attribute__((address_space(1))) uint32_t gu32;
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 
