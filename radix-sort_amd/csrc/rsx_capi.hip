@@ -175,6 +175,9 @@ struct rsx_engine {
     uint32_t* gsum8 = nullptr;                  //   per scan group: totals, then prefixes inside the group's chunk [group][256]
     uint32_t* csum8 = nullptr;                  //   per chunk of groups: totals [chunk <= 16][256]
     uint32_t* cbase8 = nullptr;                 //   per chunk: smaller digits + this digit in earlier chunks [chunk][256]
+    int self_scan = 1;          // rsx_sort: tables of at most self_scan_max tiles need no scan launch (env RSX_SELF_SCAN)
+    uint32_t self_scan_max = 512;               // env RSX_SELF_SCAN_MAX (<= 1024)
+    uint32_t* cnt3[3] = {nullptr, nullptr, nullptr};      // self-scan: three rotating [tile][16] count buffers
     int tile_sort = 1;          // rsx_sort: inputs of at most one tile are sorted by ONE workgroup in ONE launch, all passes in LDS (env RSX_TILE_SORT)
     int fold_paste = 0;         // reorder adds globsum itself (no paste launch): measured 3 % slower, off; env RSX_FOLD_PASTE
     int scan_zeroes = 1;
@@ -394,7 +397,8 @@ int launch_paste(rsx_engine* e, uint64_t count)
 // and the kernel adds the scanned block sums itself (no paste launch).
 template <typename Key, bool PAYLOAD, bool LOOKAHEAD, bool RANGED = false>
 int launch_reorder_t(rsx_engine* e, const void* in, void* out, const uint32_t* pin, uint32_t* pout, uint64_t count, int shift,
-                     uint32_t mask, int next_shift, bool fold_paste, Key lo = Key{0}, Key mul = Key{0}, uint32_t nsplit = 0)
+                     uint32_t mask, int next_shift, bool fold_paste, Key lo = Key{0}, Key mul = Key{0}, uint32_t nsplit = 0,
+                     rsx::SelfScanArgs self = rsx::SelfScanArgs{nullptr, nullptr, nullptr}, uint32_t* next_counts = nullptr)
 {
     using L = rsx::ReorderLayout<Key, kTileThreads, kKeysPerThread>;
     const Grid g = grid_for(e, count);
@@ -404,13 +408,13 @@ int launch_reorder_t(rsx_engine* e, const void* in, void* out, const uint32_t* p
     hipLaunchKernelGGL((rsx::reorder_kernel<Key, kTileThreads, kKeysPerThread, PAYLOAD, LOOKAHEAD, RANGED>), dim3(g.blocks), dim3(kTileThreads),
                        L::BYTES, e->stream, static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->table, count,
                        g.ntiles, g.tiles_per_xcd, e->xcd_remap | ((e->reverse_odd && ((shift / RSX_RADIX_BITS) & 1)) ? 2 : 0), shift, flip_mask<Key>(e), mask,
-                       e->counts_next, next_shift,
+                       next_counts ? next_counts : e->counts_next, next_shift,
 #ifdef RSX_STAMPS
                        (shift == e->stamp_pass * RSX_RADIX_BITS) ? reinterpret_cast<const uint32_t*>(e->stamps) : static_cast<const uint32_t*>(nullptr),
 #else
                        fold_paste ? static_cast<const uint32_t*>(e->globsum) : static_cast<const uint32_t*>(nullptr),
 #endif
-                       lo, mul, split_set<Key>(e, nsplit));
+                       lo, mul, split_set<Key>(e, nsplit), self);
     RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
     return RSX_OK;
 }
@@ -534,6 +538,59 @@ int sort_tile_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext_p
     return RSX_OK;
 }
 
+// Small tables (2 .. self_scan_max tiles): no scan launch at all — one histogram launch for the first pass, then one
+// reorder launch per pass; every reorder workgroup derives its own 16 bases from the raw [tile][16] counts (three
+// rotating count buffers, see rsx::SelfScanArgs).  The sort is then `passes + 1` dependent launches instead of `2 passes + 2`.
+template <typename Key>
+int sort_selfscan_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext_perm, uint64_t count)
+{
+    const Grid g = grid_for(e, count);
+    const void* in = ext_keys ? ext_keys : e->keys[e->cur];
+    const uint32_t* pin = e->has_payload ? (ext_keys ? ext_perm : e->perm[e->cur]) : nullptr;
+    int dst = ext_keys ? e->cur : (e->cur ^ 1);
+    Bracket whole(e, PH_TOTAL);
+    e->counted_keys = nullptr;
+    {
+        Bracket b(e, PH_HISTO);
+        hipLaunchKernelGGL((rsx::histogram_kernel<Key, kTileThreads, kKeysPerThread, false>), dim3(g.blocks), dim3(kTileThreads), 0, e->stream,
+                           static_cast<const Key*>(in), e->table, count, g.ntiles, g.tiles_per_xcd, e->xcd_remap, e->first_pass * RSX_RADIX_BITS,
+                           flip_mask<Key>(e), static_cast<uint32_t>(RSX_RADIX - 1), Key{0}, Key{0}, split_set<Key>(e, 0), e->cnt3[0], e->cnt3[1], e->cnt3[2]);
+        RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
+    }
+    int i = 0;
+    for (int pass = e->first_pass; pass < e->last_pass; ++pass, ++i) {
+        const bool last = pass + 1 == e->last_pass;
+        const bool to_caller = e->final_keys_out && last;
+        void* out = to_caller ? e->final_keys_out : e->keys[dst];
+        uint32_t* pout = e->has_payload ? (to_caller ? e->final_perm_out : e->perm[dst]) : nullptr;
+        const int shift = pass * RSX_RADIX_BITS;
+        const rsx::SelfScanArgs self{e->cnt3[i % 3], e->cnt3[(i + 2) % 3], last ? e->table : nullptr};
+        uint32_t* next = e->cnt3[(i + 1) % 3];
+        int rc;
+        if (e->has_payload) {
+            rc = last ? launch_reorder_t<Key, true, false>(e, in, out, pin, pout, count, shift, RSX_RADIX - 1, 0, false, Key{0}, Key{0}, 0, self, next)
+                      : launch_reorder_t<Key, true, true>(e, in, out, pin, pout, count, shift, RSX_RADIX - 1, shift + RSX_RADIX_BITS, false, Key{0}, Key{0}, 0, self, next);
+        } else {
+            rc = last ? launch_reorder_t<Key, false, false>(e, in, out, nullptr, nullptr, count, shift, RSX_RADIX - 1, 0, false, Key{0}, Key{0}, 0, self, next)
+                      : launch_reorder_t<Key, false, true>(e, in, out, nullptr, nullptr, count, shift, RSX_RADIX - 1, shift + RSX_RADIX_BITS, false, Key{0}, Key{0}, 0, self, next);
+        }
+        if (rc != RSX_OK) return rc;
+        in = out;
+        pin = pout;
+        dst ^= 1;
+    }
+    if (in == e->keys[0] || in == e->keys[1]) e->cur = (in == e->keys[0]) ? 0 : 1;
+    e->result_external = e->final_keys_out != nullptr;
+    if (e->final_keys_out) {
+        e->result_keys = e->final_keys_out;
+        e->result_perm = e->has_payload ? e->final_perm_out : nullptr;
+    } else {
+        e->result_keys = e->keys[e->cur];
+        e->result_perm = e->has_payload ? e->perm[e->cur] : nullptr;
+    }
+    return RSX_OK;
+}
+
 // 8-bit digits: per pass histogram8 -> scan8 (two launches) -> reorder8, half as many passes.  Taken by the sort
 // chain when RSX_OPT_RADIX_BITS is 8 and the pass range [first_pass, last_pass) — counted in 4-bit passes, as
 // everywhere in this API — covers whole bytes.
@@ -626,6 +683,9 @@ int sort_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext_
     }
     if (e->tile_sort && e->profile != 1 && count > 0 && count <= static_cast<uint64_t>(kTileKeys) && e->first_pass < e->last_pass) {
         return sort_tile_enqueue<Key>(e, ext_keys, ext_perm, count);
+    }
+    if (e->self_scan && e->lookahead && !e->fold_paste && count > static_cast<uint64_t>(kTileKeys) && e->ntiles(count) <= e->self_scan_max && e->first_pass < e->last_pass) {
+        return sort_selfscan_enqueue<Key>(e, ext_keys, ext_perm, count);
     }
     // Ping-pong.  With external input the first pass reads the caller's buffer (never
     // written) and the chain continues inside the engine's two buffers.
@@ -859,6 +919,8 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
     if (const char* env = std::getenv("RSX_GRAPH")) e->use_graph = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_SMALL_SCAN")) e->small_scan = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_TILE_SORT")) e->tile_sort = std::atoi(env) != 0;
+    if (const char* env = std::getenv("RSX_SELF_SCAN")) e->self_scan = std::atoi(env) != 0;
+    if (const char* env = std::getenv("RSX_SELF_SCAN_MAX")) e->self_scan_max = std::min<uint32_t>(static_cast<uint32_t>(std::atoi(env)), rsx::kSelfScanMaxTiles);
     if (const char* env = std::getenv("RSX_RADIX_BITS")) e->radix_bits = std::atoi(env) == 8 ? 8 : 4;
     if (const char* env = std::getenv("RSX_PASTE_SCAN")) e->paste_scan = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_FUSED_SCAN")) e->fused_scan = std::atoi(env) != 0;
@@ -906,6 +968,10 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
     e->globsum_live = e->globsum;
     if ((err = hipMalloc(reinterpret_cast<void**>(&e->temp), 64)) != hipSuccess)
         return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(temp)", err);
+    for (int i = 0; i < 3; ++i) {
+        if ((err = hipMalloc(reinterpret_cast<void**>(&e->cnt3[i]), rsx::kSelfScanMaxTiles * RSX_RADIX * 4)) != hipSuccess)
+            return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(self-scan counts)", err);
+    }
     if ((err = hipMalloc(reinterpret_cast<void**>(&e->gsums), rsx::kFusedScanMaxGroups * RSX_RADIX * 8)) != hipSuccess)
         return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(group sums)", err);
     if ((err = hipMemsetAsync(e->gsums, 0, rsx::kFusedScanMaxGroups * RSX_RADIX * 8, e->stream)) != hipSuccess)
@@ -987,6 +1053,9 @@ int rsx_destroy(rsx_engine* e)
     if (e->globsum2 && hipFree(e->globsum2) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->temp && hipFree(e->temp) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->gsums && hipFree(e->gsums) != hipSuccess) status = RSX_CLEANUP_FAILED;
+    for (int i = 0; i < 3; ++i) {
+        if (e->cnt3[i] && hipFree(e->cnt3[i]) != hipSuccess) status = RSX_CLEANUP_FAILED;
+    }
     if (e->counts8 && hipFree(e->counts8) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->table8 && hipFree(e->table8) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->gsum8 && hipFree(e->gsum8) != hipSuccess) status = RSX_CLEANUP_FAILED;
@@ -1053,6 +1122,7 @@ int rsx_set_option(rsx_engine* e, int option, int64_t value)
     case RSX_OPT_SMALL_SCAN: e->small_scan = value != 0; return RSX_OK;
     case RSX_OPT_TILE_SORT: e->tile_sort = value != 0; return RSX_OK;
     case RSX_OPT_FUSED_SCAN: e->fused_scan = value != 0; return RSX_OK;
+    case RSX_OPT_SELF_SCAN: e->self_scan = value != 0; return RSX_OK;
     case RSX_OPT_RADIX_BITS:
         if (value != 4 && value != 8) return fail(RSX_CALCULATION_FAILED, "rsx_set_option: digit width must be 4 or 8 bits");
         e->radix_bits = static_cast<int>(value);

@@ -181,7 +181,8 @@ template <typename Key, int THREADS, int KPT, bool RANGED = false>
 __global__ __launch_bounds__(THREADS) void histogram_kernel(const Key* __restrict__ keys, uint32_t* __restrict__ table,
                                                              uint64_t n, uint32_t ntiles, uint32_t tiles_per_xcd,
                                                              int remap, int shift, Key flip, uint32_t mask, Key lo, Key mul,
-                                                             SplitSet<Key> split)
+                                                             SplitSet<Key> split, uint32_t* __restrict__ rows_out = nullptr,
+                                                             uint32_t* __restrict__ zero_a = nullptr, uint32_t* __restrict__ zero_b = nullptr)
 {
     auto dig = [=](Key key) -> uint32_t {
         if constexpr (RANGED) {
@@ -247,7 +248,15 @@ __global__ __launch_bounds__(THREADS) void histogram_kernel(const Key* __restric
         for (int r = 0; r < REP; ++r) {
             s += cnt[r * RSTRIDE + tid];
         }
-        table[static_cast<uint64_t>(tid) * ntiles + tile] = s;
+        if (rows_out) {
+            // self-scan sorts (small tables): raw counts as one [tile][16] row, and this tile's rows of the two
+            // other rotating count buffers start from zero
+            rows_out[tile * kRadix + tid] = s;
+            zero_a[tile * kRadix + tid] = 0;
+            zero_b[tile * kRadix + tid] = 0;
+        } else {
+            table[static_cast<uint64_t>(tid) * ntiles + tile] = s;
+        }
     }
 }
 
@@ -811,7 +820,8 @@ struct ReorderLayout {
     static constexpr int WTOT_DW = 16;
     static constexpr int GBASE_DW = 2 * kRadix;             // per digit {gbase, la_base}: one ds_read_b64
     static constexpr int LA_DW = kRadix * 2 * kRadix + 16;  // look-ahead counters [digit][segment 0/1][next digit] + dummy
-    static constexpr int TOTAL_DW = XBUF_DW + CNT_DW + WTOT_DW + GBASE_DW + LA_DW;
+    static constexpr int SELF_DW = (THREADS / kWave) * 2 * kRadix + kRadix;      // self-scan: per-wave partial sums + the 16 bases
+    static constexpr int TOTAL_DW = XBUF_DW + CNT_DW + WTOT_DW + GBASE_DW + LA_DW + SELF_DW;
     static constexpr int TILE_SHIFT = __builtin_ctz(TILE);
     static_assert((TILE & (TILE - 1)) == 0, "tile size must be a power of two (slot -> output tile by shift)");
     static_assert(THREADS % (1 << PADSH) == 0, "the padded index of slot r*THREADS+t must split into a per-thread base and a constant");
@@ -834,6 +844,18 @@ constexpr int reorder_min_waves()
     return (PAYLOAD && w > cap) ? cap : w;
 }
 
+// Self-scan (tables of at most kSelfScanMaxTiles tiles): there is no scan launch — `counts` holds the RAW counts of this
+// pass as [tile][16] rows (written by the histogram kernel for the first pass, by the previous reorder's look-ahead
+// afterwards) and every workgroup derives the 16 first slots of ITS tile itself while its keys are on their way:
+// keys with a smaller digit anywhere + keys with the digit in earlier tiles.  Three count buffers rotate: this pass
+// reads one, adds the next pass's counts into the second and zeroes its tile's row of the third.
+constexpr int kSelfScanMaxTiles = 1024;
+struct SelfScanArgs {
+    const uint32_t* counts;      // nullptr: the table comes scanned (the normal path)
+    uint32_t* zero_rows;
+    uint32_t* table_out;         // last pass: leave the tile's 16 first slots in table[digit][tile] as the scan would
+};
+
 // LOOKAHEAD: while a key leaves for its slot g, the kernel also counts the key's NEXT
 // digit for the output tile g / TILE — i.e. it builds the next pass's per-tile histogram
 // (layout [tile][digit] in `next_counts`, zeroed by the host) without another pass over
@@ -851,7 +873,7 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
                                                            uint32_t tiles_per_xcd, int remap, int shift, Key flip, uint32_t mask,
                                                            uint32_t* __restrict__ next_counts, int next_shift,
                                                            const uint32_t* __restrict__ globsum, Key lo, Key mul,
-                                                           SplitSet<Key> split)
+                                                           SplitSet<Key> split, SelfScanArgs self)
 {
     using L = ReorderLayout<Key, THREADS, KPT>;
     static_assert(!(RANGED && LOOKAHEAD), "the ranged bucket function is for the one-pass partition only");
@@ -867,6 +889,8 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
     uint32_t* wtot = cnt + L::CNT_DW;
     RunBase* runs = reinterpret_cast<RunBase*>(wtot + L::WTOT_DW);
     uint32_t* la = wtot + L::WTOT_DW + L::GBASE_DW;
+    uint32_t* self_part = la + L::LA_DW;                                   // [wave][total / before][digit]
+    uint32_t* self_base = self_part + (THREADS / kWave) * 2 * kRadix;      // [digit]
 
     const uint32_t tid = threadIdx.x;
     const uint32_t slot_tile = tile_of_block(blockIdx.x, tiles_per_xcd, remap & 1);
@@ -929,7 +953,8 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
     const bool rake_head = (tid % RAKE_STRIDE) == 0;
     const uint32_t hl = tid / RAKE_STRIDE;
     uint32_t first_lo = 0, first_hi = 0;
-    if (rake_head) {
+    const bool self_scan = !RANGED && self.counts != nullptr;      // wave-uniform
+    if (rake_head && !self_scan) {
         const uint64_t e_lo = static_cast<uint64_t>(hl) * ntiles + tile;
         const uint64_t e_hi = static_cast<uint64_t>(hl + 8) * ntiles + tile;
         first_lo = table[e_lo];
@@ -979,6 +1004,59 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
                 const uint32_t li = tid * KPT + i;
                 pl[i] = li < valid ? pin[base + li] : 0u;
             }
+        }
+    }
+
+    if (self_scan) {
+        // (the key loads above are in flight; this is L2-resident table work under their latency)
+        const uint32_t d = tid & 15u, p = tid >> 4;
+        uint32_t tot = 0, pre = 0;
+        uint32_t t2 = p;
+        for (; t2 + 3 * (THREADS / kRadix) < ntiles; t2 += 4 * (THREADS / kRadix)) {
+            uint32_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[u] = self.counts[(t2 + static_cast<uint32_t>(u) * (THREADS / kRadix)) * kRadix + d];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                tot += v[u];
+                pre += (t2 + static_cast<uint32_t>(u) * (THREADS / kRadix) < tile) ? v[u] : 0u;
+            }
+        }
+        for (; t2 < ntiles; t2 += THREADS / kRadix) {
+            const uint32_t v = self.counts[t2 * kRadix + d];
+            tot += v;
+            pre += (t2 < tile) ? v : 0u;
+        }
+        tot += __shfl_xor(tot, 16);
+        pre += __shfl_xor(pre, 16);
+        tot += __shfl_xor(tot, 32);
+        pre += __shfl_xor(pre, 32);
+        const uint32_t lane = tid & (kWave - 1), wave = tid / kWave;
+        if (lane < kRadix) {
+            self_part[(wave * 2 + 0) * kRadix + lane] = tot;
+            self_part[(wave * 2 + 1) * kRadix + lane] = pre;
+        }
+        __syncthreads();
+        if (tid < kRadix) {
+            uint32_t total = 0, before = 0;
+#pragma unroll
+            for (int w = 0; w < THREADS / kWave; ++w) {
+                total += self_part[(w * 2 + 0) * kRadix + tid];
+                before += self_part[(w * 2 + 1) * kRadix + tid];
+            }
+            const uint32_t first = wave_inclusive_scan(total) - total + before;     // smaller digits anywhere + this digit in earlier tiles
+            self_base[tid] = first;
+            self.zero_rows[tile * kRadix + tid] = 0;
+            if (self.table_out) {
+                self.table_out[static_cast<uint64_t>(tid) * ntiles + tile] = first;
+            }
+        }
+        __syncthreads();
+        if (rake_head) {
+            first_lo = self_base[hl];
+            first_hi = self_base[hl + 8];
         }
     }
 

@@ -272,7 +272,14 @@ def test_timings_profile_mode(mod, oracle):
         e.upload(keys)
         e.sort()
         t = e.timings(reset=True)
-        # look-ahead: one histogram launch; 256 tiles: the one-workgroup scan does scan+paste in one launch per pass
+        # look-ahead: one histogram launch; 256 tiles: no scan launch at all (every reorder workgroup scans for itself)
+        assert t.histogram.n == 1 and t.reorder.n == 8 and t.paste.n == 0 and t.scan.n == 0
+        assert np.array_equal(e.download(), np.sort(keys))
+        e.set_option(mod.OPT_SELF_SCAN, 0)
+        e.upload(keys)
+        e.sort()
+        t = e.timings(reset=True)
+        # ... or the one-workgroup scan: scan+paste in one launch per pass
         assert t.histogram.n == 1 and t.reorder.n == 8 and t.paste.n == 0 and t.scan.n == 8
         assert np.array_equal(e.download(), np.sort(keys))
         e.set_option(mod.OPT_SMALL_SCAN, 0)
@@ -514,6 +521,7 @@ def test_fused_scan_equals_the_separate_launches(mod, oracle, dt, payload, n):
     seen = []
     for fused, small in ((1, 0), (0, 0), (1, 1)):
         with mod.Engine(dt, n, payload=payload) as e:
+            e.set_option(mod.OPT_SELF_SCAN, 0)
             e.set_option(mod.OPT_FUSED_SCAN, fused)
             e.set_option(mod.OPT_SMALL_SCAN, small)
             e.upload(keys, perm)
@@ -528,6 +536,36 @@ def test_fused_scan_equals_the_separate_launches(mod, oracle, dt, payload, n):
     for a, b in zip(seen[0], seen[1]):            # fused vs separate launches: everything, incl. table and group sums
         assert np.array_equal(a, b)
     for a, b in zip(seen[0][:-1], seen[2][:-1]):  # the one-workgroup scan of small tables leaves no group sums
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("dt,payload", [("uint32", False), ("int32", True), ("uint64", True), ("int64", False)])
+@pytest.mark.parametrize("n", [4097, 8192, 70001, (1 << 20) + 5, 1 << 21])
+def test_self_scan_equals_the_scan_launches(mod, oracle, dt, payload, n):
+    """Tables of up to 512 tiles take no scan launch: every reorder workgroup derives its own bases from the raw counts.
+    Keys, payload and the last pass's table must equal what the chain with scan launches leaves; repeated sorts rotate
+    the three count buffers through every phase."""
+    keys = oracle.dataset("SeededUniform", dt, n, seed=n + 1)
+    keys[::7] = keys[2]
+    perm = np.arange(n, dtype=np.uint32) if payload else None
+    seen = []
+    for self_scan in (1, 0):
+        with mod.Engine(dt, n, payload=payload) as e:
+            e.set_option(mod.OPT_SELF_SCAN, self_scan)
+            e.upload(keys, perm)
+            for _ in range(4):
+                e.sort()
+            g = e.geometry()
+            out = e.download(want_perm=payload, hist_cap=int(g.table_len))
+            seen.append(out)
+    assert np.array_equal(seen[0][0], np.sort(keys))
+    if payload:
+        e2 = np.argsort(keys, kind="stable").astype(np.uint32)
+        with mod.Engine(dt, n, payload=True) as e:
+            e.upload(keys, perm)
+            e.sort()
+            assert np.array_equal(e.download(want_perm=True)[1], e2)
+    for a, b in zip(seen[0], seen[1]):
         assert np.array_equal(a, b)
 
 
