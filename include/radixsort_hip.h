@@ -78,7 +78,7 @@ typedef enum rsx_option {
                                  256 runs per tile): half the passes over HBM.  Same result.  Pass ranges (RSX_OPT_FIRST_PASS /
                                  LAST_PASS, rsx_sort_from_to) stay in units of 4-bit passes and must cover whole bytes, otherwise
                                  the 4-bit chain runs; the step API and the diagnostic tables are those of 4-bit passes. */
-    RSX_OPT_SELF_SCAN = 11,   /* 1 (default): inside rsx_sort, tables of 2..512 tiles (up to 2^21 keys) get no scan launch: every reorder
+    RSX_OPT_SELF_SCAN = 11,   /* 1 (default): inside rsx_sort, tables of 2..1024 tiles (up to 2^22 keys) get no scan launch: every reorder
                                  workgroup derives the 16 first slots of its tile from the raw [tile][16] counts itself while
                                  its keys are on their way (passes + 1 dependent launches instead of 2 passes + 2) */
     RSX_OPT_LOOKAHEAD = 4     /* 1 (default): inside rsx_sort the reorder of pass p also counts pass p+1's digits per

@@ -540,9 +540,9 @@ def test_fused_scan_equals_the_separate_launches(mod, oracle, dt, payload, n):
 
 
 @pytest.mark.parametrize("dt,payload", [("uint32", False), ("int32", True), ("uint64", True), ("int64", False)])
-@pytest.mark.parametrize("n", [4097, 8192, 70001, (1 << 20) + 5, 1 << 21])
+@pytest.mark.parametrize("n", [4097, 8192, 70001, (1 << 20) + 5, 1 << 22])
 def test_self_scan_equals_the_scan_launches(mod, oracle, dt, payload, n):
-    """Tables of up to 512 tiles take no scan launch: every reorder workgroup derives its own bases from the raw counts.
+    """Tables of up to 1024 tiles take no scan launch: every reorder workgroup derives its own bases from the raw counts.
     Keys, payload and the last pass's table must equal what the chain with scan launches leaves; repeated sorts rotate
     the three count buffers through every phase."""
     keys = oracle.dataset("SeededUniform", dt, n, seed=n + 1)
