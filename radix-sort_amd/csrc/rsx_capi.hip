@@ -55,6 +55,7 @@ int fail(int status, const char* what, hipError_t err = hipSuccess)
 constexpr int kTileThreads = RSX_TILE_THREADS;
 constexpr int kKeysPerThread = RSX_KPT;
 constexpr int kTileKeys = kTileThreads * kKeysPerThread;
+constexpr int kSmallKeysPerThread = 4;      // small self-scan sorts: tiles of 1024 keys
 
 enum Phase : int { PH_HISTO = 0, PH_SCAN = 1, PH_PASTE = 2, PH_REORDER = 3, PH_TOTAL = 4, PH_COUNT = 5 };
 
@@ -178,6 +179,7 @@ struct rsx_engine {
     int self_scan = 1;          // rsx_sort: tables of at most self_scan_max tiles need no scan launch (env RSX_SELF_SCAN)
     uint32_t self_scan_max = 1024;              // env RSX_SELF_SCAN_MAX (<= 1024 tiles = 2^22 keys; measured: -36 % at 2^13..2^18, -24 % at 2^20, -11 % at 2^22)
     uint32_t* cnt3[3] = {nullptr, nullptr, nullptr};      // self-scan: three rotating [tile][16] count buffers
+    uint64_t small_tile_max_keys = 0;                     // self-scan sorts of at most this many keys use tiles of 256 x 4 keys (env RSX_SMALL_TILE_MAX_KEYS)
     int tile_sort = 1;          // rsx_sort: inputs of at most one tile are sorted by ONE workgroup in ONE launch, all passes in LDS (env RSX_TILE_SORT)
     int fold_paste = 0;         // reorder adds globsum itself (no paste launch): measured 3 % slower, off; env RSX_FOLD_PASTE
     int scan_zeroes = 1;
@@ -252,10 +254,10 @@ struct Grid {
     uint32_t ntiles, tiles_per_xcd, blocks;
 };
 
-Grid grid_for(const rsx_engine* e, uint64_t count)
+Grid grid_for(const rsx_engine* e, uint64_t count, uint32_t tile_keys = kTileKeys)
 {
     Grid g;
-    g.ntiles = static_cast<uint32_t>(e->ntiles(count));
+    g.ntiles = static_cast<uint32_t>((count + tile_keys - 1) / tile_keys);
     g.tiles_per_xcd = (g.ntiles + rsx::kNumXcd - 1) / rsx::kNumXcd;
     g.blocks = e->xcd_remap ? g.tiles_per_xcd * rsx::kNumXcd : g.ntiles;
     return g;
@@ -395,17 +397,17 @@ int launch_paste(rsx_engine* e, uint64_t count)
 // OUTPUT tile into e->counts_next (all zero on entry: zeroed at the start of the sort and handed
 // back zeroed by the scan that consumes it).  fold_paste: the table holds block-local prefixes
 // and the kernel adds the scanned block sums itself (no paste launch).
-template <typename Key, bool PAYLOAD, bool LOOKAHEAD, bool RANGED = false>
+template <typename Key, bool PAYLOAD, bool LOOKAHEAD, bool RANGED = false, int KPT = kKeysPerThread>
 int launch_reorder_t(rsx_engine* e, const void* in, void* out, const uint32_t* pin, uint32_t* pout, uint64_t count, int shift,
                      uint32_t mask, int next_shift, bool fold_paste, Key lo = Key{0}, Key mul = Key{0}, uint32_t nsplit = 0,
                      rsx::SelfScanArgs self = rsx::SelfScanArgs{nullptr, nullptr, nullptr}, uint32_t* next_counts = nullptr)
 {
-    using L = rsx::ReorderLayout<Key, kTileThreads, kKeysPerThread>;
-    const Grid g = grid_for(e, count);
+    using L = rsx::ReorderLayout<Key, kTileThreads, KPT>;
+    const Grid g = grid_for(e, count, kTileThreads * KPT);
     e->last_in = in;
     e->last_shift = shift;
     Bracket b(e, PH_REORDER);
-    hipLaunchKernelGGL((rsx::reorder_kernel<Key, kTileThreads, kKeysPerThread, PAYLOAD, LOOKAHEAD, RANGED>), dim3(g.blocks), dim3(kTileThreads),
+    hipLaunchKernelGGL((rsx::reorder_kernel<Key, kTileThreads, KPT, PAYLOAD, LOOKAHEAD, RANGED>), dim3(g.blocks), dim3(kTileThreads),
                        L::BYTES, e->stream, static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->table, count,
                        g.ntiles, g.tiles_per_xcd, e->xcd_remap | ((e->reverse_odd && ((shift / RSX_RADIX_BITS) & 1)) ? 2 : 0), shift, flip_mask<Key>(e), mask,
                        next_counts ? next_counts : e->counts_next, next_shift,
@@ -541,10 +543,13 @@ int sort_tile_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext_p
 // Small tables (2 .. self_scan_max tiles): no scan launch at all — one histogram launch for the first pass, then one
 // reorder launch per pass; every reorder workgroup derives its own 16 bases from the raw [tile][16] counts (three
 // rotating count buffers, see rsx::SelfScanArgs).  The sort is then `passes + 1` dependent launches instead of `2 passes + 2`.
-template <typename Key>
+template <typename Key, int KPT = kKeysPerThread>
 int sort_selfscan_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext_perm, uint64_t count)
 {
-    const Grid g = grid_for(e, count);
+    // KPT < 16: tiles of 256 x KPT keys for small inputs — a tile's trip through the reorder (what every pass of a small sort
+    // waits for) is a chain of per-key steps, so a quarter of the keys per thread is a shorter chain; the engine's
+    // own [digit][tile] table read-back is not produced in that geometry
+    const Grid g = grid_for(e, count, kTileThreads * KPT);
     const void* in = ext_keys ? ext_keys : e->keys[e->cur];
     const uint32_t* pin = e->has_payload ? (ext_keys ? ext_perm : e->perm[e->cur]) : nullptr;
     int dst = ext_keys ? e->cur : (e->cur ^ 1);
@@ -552,7 +557,7 @@ int sort_selfscan_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* e
     e->counted_keys = nullptr;
     {
         Bracket b(e, PH_HISTO);
-        hipLaunchKernelGGL((rsx::histogram_kernel<Key, kTileThreads, kKeysPerThread, false>), dim3(g.blocks), dim3(kTileThreads), 0, e->stream,
+        hipLaunchKernelGGL((rsx::histogram_kernel<Key, kTileThreads, KPT, false>), dim3(g.blocks), dim3(kTileThreads), 0, e->stream,
                            static_cast<const Key*>(in), e->table, count, g.ntiles, g.tiles_per_xcd, e->xcd_remap, e->first_pass * RSX_RADIX_BITS,
                            flip_mask<Key>(e), static_cast<uint32_t>(RSX_RADIX - 1), Key{0}, Key{0}, split_set<Key>(e, 0), e->cnt3[0], e->cnt3[1], e->cnt3[2]);
         RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
@@ -564,15 +569,15 @@ int sort_selfscan_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* e
         void* out = to_caller ? e->final_keys_out : e->keys[dst];
         uint32_t* pout = e->has_payload ? (to_caller ? e->final_perm_out : e->perm[dst]) : nullptr;
         const int shift = pass * RSX_RADIX_BITS;
-        const rsx::SelfScanArgs self{e->cnt3[i % 3], e->cnt3[(i + 2) % 3], last ? e->table : nullptr};
+        const rsx::SelfScanArgs self{e->cnt3[i % 3], e->cnt3[(i + 2) % 3], (last && KPT == kKeysPerThread) ? e->table : nullptr};
         uint32_t* next = e->cnt3[(i + 1) % 3];
         int rc;
         if (e->has_payload) {
-            rc = last ? launch_reorder_t<Key, true, false>(e, in, out, pin, pout, count, shift, RSX_RADIX - 1, 0, false, Key{0}, Key{0}, 0, self, next)
-                      : launch_reorder_t<Key, true, true>(e, in, out, pin, pout, count, shift, RSX_RADIX - 1, shift + RSX_RADIX_BITS, false, Key{0}, Key{0}, 0, self, next);
+            rc = last ? launch_reorder_t<Key, true, false, false, KPT>(e, in, out, pin, pout, count, shift, RSX_RADIX - 1, 0, false, Key{0}, Key{0}, 0, self, next)
+                      : launch_reorder_t<Key, true, true, false, KPT>(e, in, out, pin, pout, count, shift, RSX_RADIX - 1, shift + RSX_RADIX_BITS, false, Key{0}, Key{0}, 0, self, next);
         } else {
-            rc = last ? launch_reorder_t<Key, false, false>(e, in, out, nullptr, nullptr, count, shift, RSX_RADIX - 1, 0, false, Key{0}, Key{0}, 0, self, next)
-                      : launch_reorder_t<Key, false, true>(e, in, out, nullptr, nullptr, count, shift, RSX_RADIX - 1, shift + RSX_RADIX_BITS, false, Key{0}, Key{0}, 0, self, next);
+            rc = last ? launch_reorder_t<Key, false, false, false, KPT>(e, in, out, nullptr, nullptr, count, shift, RSX_RADIX - 1, 0, false, Key{0}, Key{0}, 0, self, next)
+                      : launch_reorder_t<Key, false, true, false, KPT>(e, in, out, nullptr, nullptr, count, shift, RSX_RADIX - 1, shift + RSX_RADIX_BITS, false, Key{0}, Key{0}, 0, self, next);
         }
         if (rc != RSX_OK) return rc;
         in = out;
@@ -685,6 +690,7 @@ int sort_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext_
         return sort_tile_enqueue<Key>(e, ext_keys, ext_perm, count);
     }
     if (e->self_scan && e->lookahead && !e->fold_paste && count > static_cast<uint64_t>(kTileKeys) && e->ntiles(count) <= e->self_scan_max && e->first_pass < e->last_pass) {
+        if (count <= e->small_tile_max_keys) return sort_selfscan_enqueue<Key, kSmallKeysPerThread>(e, ext_keys, ext_perm, count);
         return sort_selfscan_enqueue<Key>(e, ext_keys, ext_perm, count);
     }
     // Ping-pong.  With external input the first pass reads the caller's buffer (never
@@ -920,6 +926,7 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
     if (const char* env = std::getenv("RSX_SMALL_SCAN")) e->small_scan = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_TILE_SORT")) e->tile_sort = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_SELF_SCAN")) e->self_scan = std::atoi(env) != 0;
+    if (const char* env = std::getenv("RSX_SMALL_TILE_MAX_KEYS")) e->small_tile_max_keys = std::min<uint64_t>(std::strtoull(env, nullptr, 10), static_cast<uint64_t>(rsx::kSelfScanMaxTiles) * kTileThreads * kSmallKeysPerThread);
     if (const char* env = std::getenv("RSX_SELF_SCAN_MAX")) e->self_scan_max = std::min<uint32_t>(static_cast<uint32_t>(std::atoi(env)), rsx::kSelfScanMaxTiles);
     if (const char* env = std::getenv("RSX_RADIX_BITS")) e->radix_bits = std::atoi(env) == 8 ? 8 : 4;
     if (const char* env = std::getenv("RSX_PASTE_SCAN")) e->paste_scan = std::atoi(env) != 0;
@@ -1123,6 +1130,10 @@ int rsx_set_option(rsx_engine* e, int option, int64_t value)
     case RSX_OPT_TILE_SORT: e->tile_sort = value != 0; return RSX_OK;
     case RSX_OPT_FUSED_SCAN: e->fused_scan = value != 0; return RSX_OK;
     case RSX_OPT_SELF_SCAN: e->self_scan = value != 0; return RSX_OK;
+    case RSX_OPT_SMALL_TILE_MAX_KEYS:
+        if (value < 0) return fail(RSX_CALCULATION_FAILED, "rsx_set_option: negative key count");
+        e->small_tile_max_keys = std::min<uint64_t>(static_cast<uint64_t>(value), static_cast<uint64_t>(rsx::kSelfScanMaxTiles) * kTileThreads * kSmallKeysPerThread);
+        return RSX_OK;
     case RSX_OPT_RADIX_BITS:
         if (value != 4 && value != 8) return fail(RSX_CALCULATION_FAILED, "rsx_set_option: digit width must be 4 or 8 bits");
         e->radix_bits = static_cast<int>(value);

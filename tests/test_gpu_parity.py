@@ -569,6 +569,35 @@ def test_self_scan_equals_the_scan_launches(mod, oracle, dt, payload, n):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("dt,payload", [("uint32", False), ("int32", True), ("uint64", True), ("int64", False)])
+@pytest.mark.parametrize("n", [4097, 5000, 65536, 100003, 1 << 20])
+def test_small_tiles_sort_the_same(mod, oracle, dt, payload, n):
+    """Self-scan sorts on tiles of 1024 keys (4 per thread): same keys, same stable payload order; also through
+    rsx_sort_from_to with a partial pass range, and with the reference-geometry diagnostics of the host mirror."""
+    keys = oracle.dataset("SeededUniform", dt, n, seed=n + 3)
+    keys[::3] = keys[1]
+    perm = np.arange(n, dtype=np.uint32) if payload else None
+    with mod.Engine(dt, n, payload=payload) as e:
+        e.set_option(mod.OPT_SMALL_TILE_MAX_KEYS, 1 << 20)
+        e.upload(keys, perm)
+        for _ in range(4):
+            e.sort()
+        out = e.download(want_perm=payload)
+    k = out[0] if payload else out
+    assert np.array_equal(k, np.sort(keys))
+    if payload:
+        assert np.array_equal(out[1], np.argsort(keys, kind="stable").astype(np.uint32))
+    if n % 1024 == 0 and not payload:
+        want_sorted, want_table, want_gs = oracle.emulate_reference_gpu(keys)
+        with mod.Engine(dt, n) as e:
+            e.set_option(mod.OPT_SMALL_TILE_MAX_KEYS, 1 << 20)
+            e.set_option(mod.OPT_REF_DIAGNOSTICS, 1)
+            e.upload(keys)
+            e.sort()
+            got, table, gs = e.download(hist_cap=16384, globsum_cap=512)
+        assert np.array_equal(got, want_sorted) and np.array_equal(table, want_table) and np.array_equal(gs, want_gs)
+
+
 # --------------------------------------------------------------------------- one-workgroup sort of small inputs
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("n", [1, 2, 17, 1000, 1024, 4095, 4096])
