@@ -170,6 +170,7 @@ struct rsx_engine {
     int reverse_odd = 0;                        // odd passes walk the tiles backwards (env RSX_REVERSE_ODD; measured, see the tuning log)
     int lookahead = 1;          // rsx_sort builds pass p+1's histogram inside pass p's reorder
     int small_scan = 1;         // rsx_sort: one-workgroup scan+paste for tables of <= 1024 tiles (env RSX_SMALL_SCAN)
+    uint64_t radix8_min_keys = 1u << 19;        // 8-bit passes only above this many keys (env RSX_RADIX8_MIN_KEYS; at least one tile)
     int radix_bits = 4;         // RSX_OPT_RADIX_BITS: 4 (the reference's configuration) or 8 (half the passes; rsx_sort chain only)
     uint32_t* counts8 = nullptr;                // 8-bit digits: raw counts [tile][256] (allocated on first use)
     uint32_t* table8 = nullptr;                 //   group-local exclusive prefixes [tile][256]
@@ -683,7 +684,9 @@ int sort8_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext
 template <typename Key>
 int sort_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext_perm, uint64_t count)
 {
-    if (e->radix_bits == 8 && count > static_cast<uint64_t>(kTileKeys) && e->first_pass < e->last_pass && (e->first_pass & 1) == 0 && (e->last_pass & 1) == 0) {
+    // (8-bit digits pay off from 2^19 keys: below that the 4-bit self-scan chain — 9 launches of a 1024- or 4096-key tile's
+    // latency — is faster than 4 passes of four launches; same result either way)
+    if (e->radix_bits == 8 && count > e->radix8_min_keys && e->first_pass < e->last_pass && (e->first_pass & 1) == 0 && (e->last_pass & 1) == 0) {
         return sort8_chain_enqueue<Key>(e, ext_keys, ext_perm, count);
     }
     if (e->tile_sort && e->profile != 1 && count > 0 && count <= static_cast<uint64_t>(kTileKeys) && e->first_pass < e->last_pass) {
@@ -929,6 +932,7 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
     if (const char* env = std::getenv("RSX_SMALL_TILE_MAX_KEYS")) e->small_tile_max_keys = std::min<uint64_t>(std::strtoull(env, nullptr, 10), static_cast<uint64_t>(rsx::kSelfScanMaxTiles) * kTileThreads * kSmallKeysPerThread);
     if (const char* env = std::getenv("RSX_SELF_SCAN_MAX")) e->self_scan_max = std::min<uint32_t>(static_cast<uint32_t>(std::atoi(env)), rsx::kSelfScanMaxTiles);
     if (const char* env = std::getenv("RSX_RADIX_BITS")) e->radix_bits = std::atoi(env) == 8 ? 8 : 4;
+    if (const char* env = std::getenv("RSX_RADIX8_MIN_KEYS")) e->radix8_min_keys = std::max<uint64_t>(std::strtoull(env, nullptr, 10), kTileKeys);
     if (const char* env = std::getenv("RSX_PASTE_SCAN")) e->paste_scan = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_FUSED_SCAN")) e->fused_scan = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_FOLD_PASTE")) e->fold_paste = std::atoi(env) != 0;

@@ -16,6 +16,10 @@ for p in (HERE, ROOT):
         sys.path.insert(0, p)
 
 
+# the 8-bit-digit tests must reach the 8-bit kernels at test sizes (the engine keeps them for >= 2^19 keys by default)
+os.environ.setdefault("RSX_RADIX8_MIN_KEYS", "4096")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
