@@ -751,16 +751,25 @@ struct alignas(8) RunBase {
 // wave targets ONE counter (constant or sorted data: every pass of Zeros, most passes of
 // Range) the uniform branch lets lane 0 add 64 instead of 64 lanes serialising on one address.
 constexpr uint32_t kLaDummy = 2 * kRadix * kRadix;   // one spare counter past the 512 real ones
+// Every counter exists kLaReplicas times (adjacent words), odd and even lanes adding to different copies: on random data the
+// 32 lanes of one LDS pass then hit 32 different words (16 next digits x 2 copies) instead of piling two deep on 16
+// addresses.  Measured (SQ_LDS_IDX_ACTIVE): the look-ahead adds were 37 % of the fused kernel's LDS cycles, ~10 cycles per
+// wave instruction.  RSX_LA_REPLICAS=1 restores single counters.
+#ifndef RSX_LA_REPLICAS
+#define RSX_LA_REPLICAS 2
+#endif
+constexpr int kLaReplicas = RSX_LA_REPLICAS;
+static_assert(kLaReplicas == 1 || kLaReplicas == 2, "odd/even-lane replicas");
 
 __device__ __forceinline__ void lookahead_count(uint32_t* la, uint32_t idx)
 {
     const uint32_t first = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(idx)));
     if (__builtin_expect(__ballot(idx != first) == 0ull, 0)) {
         if ((threadIdx.x & (kWave - 1)) == 0) {
-            atomicAdd(&la[first], static_cast<uint32_t>(kWave));
+            atomicAdd(&la[first * kLaReplicas], static_cast<uint32_t>(kWave));
         }
     } else {
-        atomicAdd(&la[idx], 1u);
+        atomicAdd(&la[idx * kLaReplicas + (threadIdx.x & (kLaReplicas - 1))], 1u);
     }
 }
 
@@ -819,7 +828,7 @@ struct ReorderLayout {
     static constexpr int CNT_DW = 8 * THREADS;
     static constexpr int WTOT_DW = 16;
     static constexpr int GBASE_DW = 2 * kRadix;             // per digit {gbase, la_base}: one ds_read_b64
-    static constexpr int LA_DW = kRadix * 2 * kRadix + 16;  // look-ahead counters [digit][segment 0/1][next digit] + dummy
+    static constexpr int LA_DW = kLaReplicas * (kRadix * 2 * kRadix + 8);  // look-ahead counters [digit][segment 0/1][next digit][replica] + dummies
     static constexpr int SELF_DW = (THREADS / kWave) * 2 * kRadix + kRadix;      // self-scan: per-wave partial sums + the 16 bases
     static constexpr int TOTAL_DW = XBUF_DW + CNT_DW + WTOT_DW + GBASE_DW + LA_DW + SELF_DW;
     static constexpr int TILE_SHIFT = __builtin_ctz(TILE);
@@ -1264,9 +1273,10 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
         // digits) the other rounds simply add; otherwise every round is tested.
         const uint32_t first0 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(la_idx[0])));
         if (__builtin_expect(__ballot(la_idx[0] != first0) != 0ull, 1)) {
+            uint32_t* la_mine = la + (tid & (kLaReplicas - 1));      // this lane's copy of every counter
 #pragma unroll
             for (int r = 0; r < KPT; ++r) {
-                atomicAdd(&la[la_idx[r]], 1u);
+                atomicAdd(&la_mine[la_idx[r] * kLaReplicas], 1u);
             }
         } else {
 #pragma unroll
@@ -1306,7 +1316,10 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
         uint32_t first = tid;
         asm volatile("" : "+v"(first));
         for (uint32_t c = first; c < kLaDummy; c += THREADS) {
-            const uint32_t v = la[c];
+            uint32_t v = la[c * kLaReplicas];
+            if constexpr (kLaReplicas == 2) {
+                v += la[c * kLaReplicas + 1];
+            }
             if (v) {
                 // counter c = [raw digit d][segment][raw next digit]; the counts table is indexed by the TRUE next digit
                 const uint32_t d = c >> 5, seg = (c >> 4) & 1u, d2 = (c & 15u) ^ flip_next;
