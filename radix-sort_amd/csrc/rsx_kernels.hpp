@@ -751,12 +751,12 @@ struct alignas(8) RunBase {
 // wave targets ONE counter (constant or sorted data: every pass of Zeros, most passes of
 // Range) the uniform branch lets lane 0 add 64 instead of 64 lanes serialising on one address.
 constexpr uint32_t kLaDummy = 2 * kRadix * kRadix;   // one spare counter past the 512 real ones
-// Every counter exists kLaReplicas times (adjacent words), odd and even lanes adding to different copies: on random data the
-// 32 lanes of one LDS pass then hit 32 different words (16 next digits x 2 copies) instead of piling two deep on 16
-// addresses.  Measured (SQ_LDS_IDX_ACTIVE): the look-ahead adds were 37 % of the fused kernel's LDS cycles, ~10 cycles per
-// wave instruction.  RSX_LA_REPLICAS=1 restores single counters.
+// Optional (-DRSX_LA_REPLICAS=2): every counter in two adjacent copies, odd and even lanes adding to different ones, so that the 32
+// lanes of one LDS pass hit 32 different words instead of piling two deep on 16 addresses.  Measured in both rounds: no difference
+// at steady state (3.607-3.613 ms per sort either way) — SQ counters put the look-ahead adds at 37 % of the fused kernel's LDS
+// cycles, but at full clock the kernel waits for HBM, not for LDS.  One copy is the default (less LDS).
 #ifndef RSX_LA_REPLICAS
-#define RSX_LA_REPLICAS 2
+#define RSX_LA_REPLICAS 1
 #endif
 constexpr int kLaReplicas = RSX_LA_REPLICAS;
 static_assert(kLaReplicas == 1 || kLaReplicas == 2, "odd/even-lane replicas");
