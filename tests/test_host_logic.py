@@ -109,3 +109,14 @@ def test_bench_launcher_propagates_a_failing_rank():
     """A rank that dies must make `python bench.py --gpus N` exit non-zero and print no result line."""
     proc, line = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--total-log2-keys", "0"], {"RSX_BENCH_REHEARSAL": "1"}, timeout=300)
     assert proc.returncode != 0 and line is None            # 2^0 keys do not divide over two ranks
+
+
+def test_bench_rehearsal_eight_ranks_is_config_4_shaped():
+    """The driver's scaling run ends at `--gpus 8`: eight ranks, two pipelined waves of one top-nibble bucket per rank, the
+    capacity verdict from gathered data, the verification gather — rehearsed on the CPU test double (2^17 keys in total)."""
+    proc, line = _run_bench(["--gpus", "8", "--steps", "1", "--warmup", "1", "--total-log2-keys", "17", "--cpu-sample-log2", "10"],
+                            {"RSX_BENCH_REHEARSAL": "1"}, timeout=900)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-3000:]
+    assert line["n_gpus"] == 8 and line["config"]["keys_per_gpu"] == 1 << 14 and line["scaling"] == "strong"
+    assert "waves" in line["config"]["parallelism"] and "x8" in line["config"]["parallelism"]
+    assert line["config"]["verified"].startswith("bit-exact vs a host sort of all 131072 keys")
