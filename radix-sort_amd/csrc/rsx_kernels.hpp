@@ -755,6 +755,9 @@ constexpr uint32_t kLaDummy = 2 * kRadix * kRadix;   // one spare counter past t
 // lanes of one LDS pass hit 32 different words instead of piling two deep on 16 addresses.  Measured in both rounds: no difference
 // at steady state (3.607-3.613 ms per sort either way) — SQ counters put the look-ahead adds at 37 % of the fused kernel's LDS
 // cycles, but at full clock the kernel waits for HBM, not for LDS.  One copy is the default (less LDS).
+#ifndef RSX_EARLY_RANK
+#define RSX_EARLY_RANK 1
+#endif
 #ifndef RSX_LA_REPLICAS
 #define RSX_LA_REPLICAS 1
 #endif
@@ -1115,6 +1118,9 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
         for (int i = 0; i < KPT; ++i) {
             const uint32_t sh4 = bucket_at(i) << 2;
             slot[i] = static_cast<uint32_t>(seen >> sh4) & 15u;
+#if RSX_EARLY_RANK
+            asm volatile("" : "+v"(slot[i]));      // materialise the rank now: otherwise hipcc keeps all 16 intermediate `seen` values (32 VGPRs) and extracts the ranks after the loop
+#endif
             if (i + 1 < KPT) {
                 seen += 1ull << sh4;
             }
