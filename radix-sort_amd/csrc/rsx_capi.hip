@@ -403,7 +403,7 @@ int launch_reorder_t(rsx_engine* e, const void* in, void* out, const uint32_t* p
                      uint32_t mask, int next_shift, bool fold_paste, Key lo = Key{0}, Key mul = Key{0}, uint32_t nsplit = 0,
                      rsx::SelfScanArgs self = rsx::SelfScanArgs{nullptr, nullptr, nullptr}, uint32_t* next_counts = nullptr)
 {
-    using L = rsx::ReorderLayout<Key, kTileThreads, KPT>;
+    using L = rsx::ReorderLayout<Key, kTileThreads, KPT, (!RANGED && RSX_ALIAS_COUNTERS != 0)>;
     const Grid g = grid_for(e, count, kTileThreads * KPT);
     e->last_in = in;
     e->last_shift = shift;
@@ -439,7 +439,7 @@ int launch_reorder(rsx_engine* e, const void* in, void* out, const uint32_t* pin
 template <typename Key, bool PAYLOAD, bool LOOKAHEAD, bool RANGED = false>
 int allow_lds()
 {
-    using L = rsx::ReorderLayout<Key, kTileThreads, kKeysPerThread>;
+    using L = rsx::ReorderLayout<Key, kTileThreads, kKeysPerThread, (!RANGED && RSX_ALIAS_COUNTERS != 0)>;
     RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder_kernel<Key, kTileThreads, kKeysPerThread, PAYLOAD, LOOKAHEAD, RANGED>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L::BYTES)),
             RSX_INITIALIZATION_FAILED);

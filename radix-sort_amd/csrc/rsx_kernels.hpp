@@ -821,7 +821,14 @@ __device__ __forceinline__ uint32_t field_word(uint64_t key, bool hi) { return h
 #define RSX_STAMP(k) do { } while (0)
 #endif
 
-template <typename Key, int THREADS, int KPT>
+// ALIAS: the packed counters share LDS with the staging image (they are dead once every thread has read its 16
+// "first slot of my digit" values, which is when the image starts to fill; one extra barrier in between).  That takes
+// a uint32 tile from 28 to 20 KiB and a uint64 tile from 46 to 37 KiB: 6 instead of 5, and 4 instead of 3, resident
+// workgroups per CU.  The partition kernels (RANGED) reuse the counter area for the staged bucket bytes and do not alias.
+#ifndef RSX_ALIAS_COUNTERS
+#define RSX_ALIAS_COUNTERS 1
+#endif
+template <typename Key, int THREADS, int KPT, bool ALIAS = (RSX_ALIAS_COUNTERS != 0)>
 struct ReorderLayout {
     static constexpr int TILE = THREADS * KPT;
     static constexpr int KD = sizeof(Key) / 4;
@@ -829,29 +836,32 @@ struct ReorderLayout {
     static constexpr int XELEMS = TILE + (TILE >> PADSH);
     static constexpr int XBUF_DW = XELEMS * KD;
     static constexpr int CNT_DW = 8 * THREADS;
+    static constexpr int CNT_AT = ALIAS ? 0 : XBUF_DW;                              // dword offset of the counters
+    static constexpr int IMAGE_DW = ALIAS ? (XBUF_DW > CNT_DW ? XBUF_DW : CNT_DW) : XBUF_DW + CNT_DW;
     static constexpr int WTOT_DW = 16;
     static constexpr int GBASE_DW = 2 * kRadix;             // per digit {gbase, la_base}: one ds_read_b64
     static constexpr int LA_DW = kLaReplicas * (kRadix * 2 * kRadix + 8);  // look-ahead counters [digit][segment 0/1][next digit][replica] + dummies
     static constexpr int SELF_DW = (THREADS / kWave) * 2 * kRadix + kRadix;      // self-scan: per-wave partial sums + the 16 bases
-    static constexpr int TOTAL_DW = XBUF_DW + CNT_DW + WTOT_DW + GBASE_DW + LA_DW + SELF_DW;
+    static constexpr int TOTAL_DW = IMAGE_DW + WTOT_DW + GBASE_DW + LA_DW + SELF_DW;
     static constexpr int TILE_SHIFT = __builtin_ctz(TILE);
     static_assert((TILE & (TILE - 1)) == 0, "tile size must be a power of two (slot -> output tile by shift)");
     static_assert(THREADS % (1 << PADSH) == 0, "the padded index of slot r*THREADS+t must split into a per-thread base and a constant");
     static constexpr size_t BYTES = static_cast<size_t>(TOTAL_DW) * 4;
-    // Workgroups one CU can hold by LDS (160 KiB) -> waves per SIMD the register allocator must
-    // leave room for (second __launch_bounds__ argument = waves per SIMD, not blocks per CU).
+    // Workgroups one CU can hold by LDS (160 KiB) -> waves per SIMD the register allocator must leave room for (second
+    // __launch_bounds__ argument = waves per SIMD, not blocks per CU); never asked beyond 6 (80 VGPRs: what the keys-only
+    // kernels need; 8 would mean 64 and spills).
     static constexpr int WGS_PER_CU = static_cast<int>((160 * 1024) / BYTES);
-    static constexpr int MIN_WAVES = (WGS_PER_CU * THREADS / 256) > 8 ? 8 : (WGS_PER_CU * THREADS / 256);
+    static constexpr int MIN_WAVES = (WGS_PER_CU * THREADS / 256) > 6 ? 6 : (WGS_PER_CU * THREADS / 256);
     static_assert(TILE <= 32768, "16-bit packed counters");
     static_assert(KPT % (16 / sizeof(Key)) == 0 && THREADS % 64 == 0 && THREADS % 8 == 0, "geometry");
 };
 
 // Register budget: keys-only kernels are held to the occupancy LDS allows; payload kernels carry
 // twice the per-key state (key, slot, payload, target) and are given 128 VGPRs instead of spilling.
-template <typename Key, int THREADS, int KPT, bool PAYLOAD>
+template <typename Key, int THREADS, int KPT, bool PAYLOAD, bool RANGED = false>
 constexpr int reorder_min_waves()
 {
-    constexpr int w = ReorderLayout<Key, THREADS, KPT>::MIN_WAVES;
+    constexpr int w = ReorderLayout<Key, THREADS, KPT, (!RANGED && RSX_ALIAS_COUNTERS != 0)>::MIN_WAVES;
     constexpr int cap = 4 * THREADS / 256;
     return (PAYLOAD && w > cap) ? cap : w;
 }
@@ -879,7 +889,7 @@ struct SelfScanArgs {
 // key): the sign bit only ever toggles the top bit of the top digit, which is folded into where the
 // counters, the run bases and the flushed counts are PLACED (flip_cur / flip_next below).
 template <typename Key, int THREADS, int KPT, bool PAYLOAD, bool LOOKAHEAD, bool RANGED = false>
-__global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYLOAD>())) void reorder_kernel(const Key* __restrict__ in, Key* __restrict__ out,
+__global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYLOAD, RANGED>())) void reorder_kernel(const Key* __restrict__ in, Key* __restrict__ out,
                                                            const uint32_t* __restrict__ pin, uint32_t* __restrict__ pout,
                                                            const uint32_t* __restrict__ table, uint64_t n, uint32_t ntiles,
                                                            uint32_t tiles_per_xcd, int remap, int shift, Key flip, uint32_t mask,
@@ -887,7 +897,7 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
                                                            const uint32_t* __restrict__ globsum, Key lo, Key mul,
                                                            SplitSet<Key> split, SelfScanArgs self)
 {
-    using L = ReorderLayout<Key, THREADS, KPT>;
+    using L = ReorderLayout<Key, THREADS, KPT, (!RANGED && RSX_ALIAS_COUNTERS != 0)>;
     static_assert(!(RANGED && LOOKAHEAD), "the ranged bucket function is for the one-pass partition only");
     constexpr bool RAW = LOOKAHEAD;                 // digits are raw 4-bit fields; the sign flip lives in the placement
     constexpr int TILE = L::TILE;
@@ -897,8 +907,8 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
 
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* xbuf = smem;
-    uint32_t* cnt = smem + L::XBUF_DW;
-    uint32_t* wtot = cnt + L::CNT_DW;
+    uint32_t* cnt = smem + L::CNT_AT;
+    uint32_t* wtot = smem + L::IMAGE_DW;
     RunBase* runs = reinterpret_cast<RunBase*>(wtot + L::WTOT_DW);
     uint32_t* la = wtot + L::WTOT_DW + L::GBASE_DW;
     uint32_t* self_part = la + L::LA_DW;                                   // [wave][total / before][digit]
@@ -1202,6 +1212,9 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
             slot[i] += first_of_digit[i];
+        }
+        if constexpr (L::CNT_AT == 0) {
+            __syncthreads();                 // the image overlays the counters: nobody may still be reading them
         }
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
