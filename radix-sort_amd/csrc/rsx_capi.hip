@@ -1038,6 +1038,7 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
     }
     e->result_keys = e->keys[0];
     e->result_perm = e->perm[0];
+    if (std::getenv("RSX_DEBUG_PTRS")) std::fprintf(stderr, "[radixsort_hip] keys[0]=%p keys[1]=%p table=%p counts_next=%p\n", e->keys[0], e->keys[1], static_cast<void*>(e->table), static_cast<void*>(e->counts_next));
     *out = e;
     return RSX_OK;
 }

@@ -975,7 +975,10 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
     const bool rake_head = (tid % RAKE_STRIDE) == 0;
     const uint32_t hl = tid / RAKE_STRIDE;
     uint32_t first_lo = 0, first_hi = 0;
-    const bool self_scan = !RANGED && self.counts != nullptr;      // wave-uniform
+#ifndef RSX_SELF_SCAN_KERNEL
+#define RSX_SELF_SCAN_KERNEL 1
+#endif
+    const bool self_scan = RSX_SELF_SCAN_KERNEL && !RANGED && self.counts != nullptr;      // wave-uniform
     if (rake_head && !self_scan) {
         const uint64_t e_lo = static_cast<uint64_t>(hl) * ntiles + tile;
         const uint64_t e_hi = static_cast<uint64_t>(hl + 8) * ntiles + tile;
