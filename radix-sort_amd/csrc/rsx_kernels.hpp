@@ -821,12 +821,14 @@ __device__ __forceinline__ uint32_t field_word(uint64_t key, bool hi) { return h
 #define RSX_STAMP(k) do { } while (0)
 #endif
 
-// ALIAS: the packed counters share LDS with the staging image (they are dead once every thread has read its 16
-// "first slot of my digit" values, which is when the image starts to fill; one extra barrier in between).  That takes
-// a uint32 tile from 28 to 20 KiB and a uint64 tile from 46 to 37 KiB: 6 instead of 5, and 4 instead of 3, resident
-// workgroups per CU.  The partition kernels (RANGED) reuse the counter area for the staged bucket bytes and do not alias.
+// ALIAS (optional, -DRSX_ALIAS_COUNTERS=1): the packed counters share LDS with the staging image (they are dead once every thread
+// has read its 16 "first slot of my digit" values, which is when the image starts to fill; one extra barrier in between).  That
+// takes a uint32 tile from 28 to 20 KiB and a uint64 tile from 46 to 37 KiB: 6 instead of 5, and 4 instead of 3, resident
+// workgroups per CU.  Measured with six interleaved runs per build (the runs are bimodal, 2-3 % apart, so pairs mislead):
+// uint32 3.67 / 3.76 ms against 3.62 / 3.71 without, uint64 13.15-13.43 against 12.92-13.34, uint64+payload 18.04-18.20 against
+// 18.19-18.29 — the barrier costs more than the occupancy gives.  Off.
 #ifndef RSX_ALIAS_COUNTERS
-#define RSX_ALIAS_COUNTERS 1
+#define RSX_ALIAS_COUNTERS 0
 #endif
 template <typename Key, int THREADS, int KPT, bool ALIAS = (RSX_ALIAS_COUNTERS != 0)>
 struct ReorderLayout {
