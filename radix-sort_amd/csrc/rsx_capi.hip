@@ -91,6 +91,7 @@ struct GraphEntry {      // one captured rsx_sort chain
     const uint32_t* pin;
     uint64_t n;
     int cur, first, last, flags;
+    uint64_t options_epoch;      // rsx_set_option calls seen when the chain was captured: an option may change the launches
     hipStream_t stream;
     hipGraphExec_t exec;
     int end_cur;
@@ -167,6 +168,8 @@ struct rsx_engine {
 
     int profile = 0;            // 0 off, 1 every launch, 2 reorder launches (+ whole sort) only
     int xcd_remap = 1;
+    uint64_t options_epoch = 0;
+    int64_t xcd_phase = -1;     // RSX_OPT_XCD_PHASE / env RSX_XCD_PHASE, in tiles: -1 = a range's eighth (the XCDs spread evenly over the walk), 0 = lockstep
     int reverse_odd = 0;                        // odd passes walk the tiles backwards (env RSX_REVERSE_ODD; measured, see the tuning log)
     int lookahead = 1;          // rsx_sort builds pass p+1's histogram inside pass p's reorder
     int small_scan = 1;         // rsx_sort: one-workgroup scan+paste for tables of <= 1024 tiles (env RSX_SMALL_SCAN)
@@ -253,6 +256,7 @@ Key flip_mask(const rsx_engine* e)
 
 struct Grid {
     uint32_t ntiles, tiles_per_xcd, blocks;
+    int remap;        // kernel argument: bit 0 = XCD-contiguous tile ranges, bits 8.. = phase stagger between the XCDs (tiles)
 };
 
 Grid grid_for(const rsx_engine* e, uint64_t count, uint32_t tile_keys = kTileKeys)
@@ -261,6 +265,11 @@ Grid grid_for(const rsx_engine* e, uint64_t count, uint32_t tile_keys = kTileKey
     g.ntiles = static_cast<uint32_t>((count + tile_keys - 1) / tile_keys);
     g.tiles_per_xcd = (g.ntiles + rsx::kNumXcd - 1) / rsx::kNumXcd;
     g.blocks = e->xcd_remap ? g.tiles_per_xcd * rsx::kNumXcd : g.ntiles;
+    // XCD x enters its range x * phase tiles in (rsx::tile_of_block): ranges that start n/8 apart walked in lockstep keep the
+    // eight XCDs on the same HBM channels (-6 % at 2^28 keys, profiles/r02_tuning_log.md §6)
+    const uint64_t want = e->xcd_phase < 0 ? g.tiles_per_xcd / rsx::kNumXcd : static_cast<uint64_t>(e->xcd_phase);
+    const uint32_t phase = (e->xcd_remap && (rsx::kNumXcd - 1) * want < g.tiles_per_xcd) ? static_cast<uint32_t>(want) : 0u;
+    g.remap = (e->xcd_remap ? 1 : 0) | static_cast<int>(phase << 8);
     return g;
 }
 
@@ -283,7 +292,7 @@ int launch_histogram(rsx_engine* e, const void* in, uint64_t count, int shift, u
     const Grid g = grid_for(e, count);
     Bracket b(e, PH_HISTO);
     hipLaunchKernelGGL((rsx::histogram_kernel<Key, kTileThreads, kKeysPerThread, RANGED>), dim3(g.blocks), dim3(kTileThreads), 0, e->stream,
-                       static_cast<const Key*>(in), e->table, count, g.ntiles, g.tiles_per_xcd, e->xcd_remap, shift,
+                       static_cast<const Key*>(in), e->table, count, g.ntiles, g.tiles_per_xcd, g.remap, shift,
                        flip_mask<Key>(e), mask, lo, mul, split_set<Key>(e, nsplit));
     RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
     return RSX_OK;
@@ -410,7 +419,7 @@ int launch_reorder_t(rsx_engine* e, const void* in, void* out, const uint32_t* p
     Bracket b(e, PH_REORDER);
     hipLaunchKernelGGL((rsx::reorder_kernel<Key, kTileThreads, KPT, PAYLOAD, LOOKAHEAD, RANGED>), dim3(g.blocks), dim3(kTileThreads),
                        L::BYTES, e->stream, static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->table, count,
-                       g.ntiles, g.tiles_per_xcd, e->xcd_remap | ((e->reverse_odd && ((shift / RSX_RADIX_BITS) & 1)) ? 2 : 0), shift, flip_mask<Key>(e), mask,
+                       g.ntiles, g.tiles_per_xcd, g.remap | ((e->reverse_odd && ((shift / RSX_RADIX_BITS) & 1)) ? 2 : 0), shift, flip_mask<Key>(e), mask,
                        next_counts ? next_counts : e->counts_next, next_shift,
 #ifdef RSX_STAMPS
                        (shift == e->stamp_pass * RSX_RADIX_BITS) ? reinterpret_cast<const uint32_t*>(e->stamps) : static_cast<const uint32_t*>(nullptr),
@@ -559,7 +568,7 @@ int sort_selfscan_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* e
     {
         Bracket b(e, PH_HISTO);
         hipLaunchKernelGGL((rsx::histogram_kernel<Key, kTileThreads, KPT, false>), dim3(g.blocks), dim3(kTileThreads), 0, e->stream,
-                           static_cast<const Key*>(in), e->table, count, g.ntiles, g.tiles_per_xcd, e->xcd_remap, e->first_pass * RSX_RADIX_BITS,
+                           static_cast<const Key*>(in), e->table, count, g.ntiles, g.tiles_per_xcd, g.remap, e->first_pass * RSX_RADIX_BITS,
                            flip_mask<Key>(e), static_cast<uint32_t>(RSX_RADIX - 1), Key{0}, Key{0}, split_set<Key>(e, 0), e->cnt3[0], e->cnt3[1], e->cnt3[2]);
         RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
     }
@@ -635,7 +644,7 @@ int sort8_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext
         {
             Bracket b(e, PH_HISTO);
             hipLaunchKernelGGL((rsx::histogram8_kernel<Key, kTileThreads, kKeysPerThread>), dim3(g.blocks), dim3(kTileThreads), 0, e->stream,
-                               static_cast<const Key*>(in), e->counts8, count, g.ntiles, g.tiles_per_xcd, e->xcd_remap, shift, flip);
+                               static_cast<const Key*>(in), e->counts8, count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip);
         }
         {
             Bracket b(e, PH_SCAN);
@@ -655,11 +664,11 @@ int sort8_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext
             if (e->has_payload) {
                 hipLaunchKernelGGL((rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, true>), dim3(g.blocks), dim3(kTileThreads), L::BYTES, e->stream,
                                    static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->counts8, e->table8, e->gsum8, e->cbase8, chunk_groups,
-                                   count, g.ntiles, g.tiles_per_xcd, e->xcd_remap, shift, flip);
+                                   count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip);
             } else {
                 hipLaunchKernelGGL((rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, false>), dim3(g.blocks), dim3(kTileThreads), L::BYTES, e->stream,
                                    static_cast<const Key*>(in), static_cast<Key*>(out), nullptr, nullptr, e->counts8, e->table8, e->gsum8, e->cbase8, chunk_groups,
-                                   count, g.ntiles, g.tiles_per_xcd, e->xcd_remap, shift, flip);
+                                   count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip);
             }
         }
         RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
@@ -776,10 +785,11 @@ int sort_chain(rsx_engine* e, const void* ext_keys, const uint32_t* ext_perm, ui
     key.first = e->first_pass;
     key.last = e->last_pass;
     key.flags = (e->lookahead ? 1 : 0) | (e->xcd_remap ? 2 : 0) | (e->fold_paste ? 4 : 0) | (e->scan_zeroes ? 8 : 0) | (e->small_scan ? 16 : 0);
+    key.options_epoch = e->options_epoch;
     key.stream = e->stream;
     for (const GraphEntry& g : e->graphs) {
         if (g.in == key.in && g.pin == key.pin && g.n == key.n && g.cur == key.cur && g.first == key.first && g.last == key.last &&
-            g.flags == key.flags && g.stream == key.stream) {
+            g.flags == key.flags && g.options_epoch == key.options_epoch && g.stream == key.stream) {
             RSX_TRY(hipGraphLaunch(g.exec, e->stream), RSX_CALCULATION_FAILED);
             e->cur = g.end_cur;
             e->last_in = g.end_last_in;
@@ -923,6 +933,7 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
     e->last_pass = static_cast<int>(e->passes());
     for (auto& s : e->stats) stat_reset(s);
     if (const char* env = std::getenv("RSX_XCD_REMAP")) e->xcd_remap = std::atoi(env) != 0;
+    if (const char* env = std::getenv("RSX_XCD_PHASE")) e->xcd_phase = std::atoll(env);
     if (const char* env = std::getenv("RSX_REVERSE_ODD")) e->reverse_odd = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_LOOKAHEAD")) e->lookahead = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_GRAPH")) e->use_graph = std::atoi(env) != 0;
@@ -1125,6 +1136,7 @@ int rsx_get_stream(const rsx_engine* e, void** hip_stream)
 int rsx_set_option(rsx_engine* e, int option, int64_t value)
 {
     if (!e) return fail(RSX_INITIALIZATION_FAILED, "rsx_set_option: null engine");
+    ++e->options_epoch;          // captured chains of the old settings are not replayed (sort_chain)
     switch (option) {
     case RSX_OPT_PROFILE: e->profile = value < 0 || value > 2 ? 1 : static_cast<int>(value); return RSX_OK;
     case RSX_OPT_XCD_REMAP: e->xcd_remap = value != 0; return RSX_OK;
@@ -1138,6 +1150,10 @@ int rsx_set_option(rsx_engine* e, int option, int64_t value)
     case RSX_OPT_SMALL_TILE_MAX_KEYS:
         if (value < 0) return fail(RSX_CALCULATION_FAILED, "rsx_set_option: negative key count");
         e->small_tile_max_keys = std::min<uint64_t>(static_cast<uint64_t>(value), static_cast<uint64_t>(rsx::kSelfScanMaxTiles) * kTileThreads * kSmallKeysPerThread);
+        return RSX_OK;
+    case RSX_OPT_XCD_PHASE:
+        if (value < -1 || value > (1 << 22)) return fail(RSX_CALCULATION_FAILED, "rsx_set_option: XCD phase out of range");
+        e->xcd_phase = value;
         return RSX_OK;
     case RSX_OPT_RADIX_BITS:
         if (value != 4 && value != 8) return fail(RSX_CALCULATION_FAILED, "rsx_set_option: digit width must be 4 or 8 bits");

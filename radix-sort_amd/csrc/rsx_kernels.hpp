@@ -124,9 +124,20 @@ __device__ __forceinline__ uint32_t splitter_bucket(Key x, const SplitSet<Key>& 
 // of tiles, so the seam between the output runs of tiles t and t+1 (same digit,
 // adjacent addresses, usually inside one 128-B line) meets in ONE L2 and is merged
 // before it goes to HBM; the [digit][tile] table rows are written the same way.
+//
+// Phase (bits 8.. of `remap`, in tiles): XCD x starts its walk `x * phase` tiles into its range and wraps round.  Without it the
+// eight XCDs advance in lockstep through ranges that start exactly n/8 apart (128 MiB at 2^28 uint32 keys), i.e. at any moment
+// their eight read streams (and the 8 x 16 write streams) sit on identical low address bits and pile onto the same HBM channels:
+// measured 3.57-3.69 ms per sort in lockstep against 3.34-3.40 ms staggered (profiles/r02_tuning_log.md §6).
 __device__ __forceinline__ uint32_t tile_of_block(uint32_t bid, uint32_t tiles_per_xcd, int remap)
 {
-    return remap ? (bid % kNumXcd) * tiles_per_xcd + bid / kNumXcd : bid;
+    if (!(remap & 1)) {
+        return bid;
+    }
+    const uint32_t x = bid % kNumXcd;
+    uint32_t j = bid / kNumXcd + x * (static_cast<uint32_t>(remap) >> 8);      // host keeps 7 * phase < tiles_per_xcd
+    j = j >= tiles_per_xcd ? j - tiles_per_xcd : j;
+    return x * tiles_per_xcd + j;
 }
 
 // Inclusive prefix sum across the 64 lanes of a wave with DPP only (no LDS traffic):
@@ -917,7 +928,7 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
     uint32_t* self_base = self_part + (THREADS / kWave) * 2 * kRadix;      // [digit]
 
     const uint32_t tid = threadIdx.x;
-    const uint32_t slot_tile = tile_of_block(blockIdx.x, tiles_per_xcd, remap & 1);
+    const uint32_t slot_tile = tile_of_block(blockIdx.x, tiles_per_xcd, remap & ~2);
     if (slot_tile >= ntiles) {
         return;
     }
@@ -1776,7 +1787,7 @@ __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREAD
     uint32_t* wtot = cnt + L::CNT_DW;
     uint32_t* gb = wtot + 16;                     // per 8-bit digit: (global slot of the tile's first key with it) - (its local slot)
     const uint32_t tid = threadIdx.x;
-    const uint32_t tile = tile_of_block(blockIdx.x, tiles_per_xcd, remap & 1);
+    const uint32_t tile = tile_of_block(blockIdx.x, tiles_per_xcd, remap & ~2);
     if (tile >= ntiles) {
         return;
     }

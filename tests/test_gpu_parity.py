@@ -600,6 +600,37 @@ def test_small_tiles_sort_the_same(mod, oracle, dt, payload, n):
         assert np.array_equal(got, want_sorted) and np.array_equal(table, want_table) and np.array_equal(gs, want_gs)
 
 
+# --------------------------------------------------------------------------- XCD phase stagger (placement only)
+@pytest.mark.parametrize("bits", [4, 8])
+@pytest.mark.parametrize("dt,payload", [("uint32", False), ("int64", True)])
+@pytest.mark.parametrize("n", [(1 << 22) + 4096 * 8 + 77, 2130003, 1 << 23])
+def test_xcd_phase_is_placement_only(mod, oracle, dt, payload, n, bits):
+    """RSX_OPT_XCD_PHASE moves where each XCD enters its tile range (rsx::tile_of_block); every tile must still be
+    sorted exactly once whatever the phase: lockstep (0), the default (-1), one tile, the largest phase the
+    range admits, and one past it (falls back to lockstep).  Sizes: a ragged last range, an odd tile count, 2^23."""
+    keys = oracle.dataset("SeededUniform", dt, n, seed=n + bits)
+    keys[::5] = keys[2]
+    perm = np.arange(n, dtype=np.uint32) if payload else None
+    want = np.sort(keys)
+    want_perm = np.argsort(keys, kind="stable").astype(np.uint32) if payload else None
+    tiles_per_xcd = ((n + 4095) // 4096 + 7) // 8
+    limit = (tiles_per_xcd - 1) // 7
+    for phase in (0, -1, 1, limit, limit + 1):
+        with mod.Engine(dt, n, payload=payload) as e:
+            e.set_option(mod.OPT_RADIX_BITS, bits)
+            e.set_option(mod.OPT_XCD_PHASE, phase)
+            e.upload(keys, perm)
+            e.sort()
+            out = e.download(want_perm=payload)
+        k = out[0] if payload else out
+        assert np.array_equal(k, want), phase
+        if payload:
+            assert np.array_equal(out[1], want_perm), phase
+    with mod.Engine(dt, 4096) as e:
+        with pytest.raises(mod.RadixSortError):
+            e.set_option(mod.OPT_XCD_PHASE, -2)
+
+
 # --------------------------------------------------------------------------- one-workgroup sort of small inputs
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("n", [1, 2, 17, 1000, 1024, 4095, 4096])

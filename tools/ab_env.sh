@@ -1,8 +1,12 @@
 #!/bin/bash
-# Interleaved A/B of one environment switch on ONE box: tools/ab_env.sh VAR "v1 v2 ..." [rounds] [bench args]
-VAR=$1; VALS=$2; ROUNDS=${3:-2}; shift 3
-for r in $(seq $ROUNDS); do for v in $VALS; do
-env $VAR=$v python bench.py --no-cpu-baseline --steps 20 "$@" | python -c "
-import sys,json
-d=json.loads(sys.stdin.read()); print('r$r $VAR=$v', d['config']['workload'][:24], d['value'], d['ms_per_step'], 'reorder', d['roofline']['avg_launch_ms'], d['roofline']['frac'])"
-done; done
+# ab_env.sh VAR=VALUE [rounds] [bench args]: ms per sort of the product with and without one environment setting, interleaved, printed sorted
+# (runs of one build are bimodal, 2-3 % apart: compare the sorted lists, not single runs)
+S=$1; R=${2:-6}; shift 2
+one () { python bench.py --no-cpu-baseline --no-verify --steps 40 --warmup 10 "$@" 2>/dev/null | python -c "import json,sys; print(json.loads(sys.stdin.read())['ms_per_step'])"; }
+p=""; v=""
+for i in $(seq 1 $R); do
+  p="$p $(one "$@")"
+  v="$v $(env $S python bench.py --no-cpu-baseline --no-verify --steps 40 --warmup 10 "$@" 2>/dev/null | python -c "import json,sys; print(json.loads(sys.stdin.read())['ms_per_step'])")"
+done
+echo "[$*] default: $(echo $p | tr ' ' '\n' | sort -n | tr '\n' ' ')"
+echo "[$*] $S: $(echo $v | tr ' ' '\n' | sort -n | tr '\n' ' ')"

@@ -1,0 +1,34 @@
+"""Runs of one build on one box come in two modes 2-3 % apart.  Is the mode a property of the process, or of where the buffers sit?
+Several engines alive at once in ONE process (different allocations), each timed on the same device-resident input."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as entry
+
+m = entry.load_package()
+n = 1 << 28
+keys = torch.from_numpy(np.random.default_rng(1).integers(0, 2**32, size=n, dtype=np.uint32).view(np.int32)).cuda()
+stream = torch.cuda.Stream()
+torch.cuda.set_stream(stream)
+engines = []
+for i in range(5):
+    e = m.Engine("uint32", n)
+    e.set_stream(stream.cuda_stream)
+    engines.append(e)
+    if i % 2 == 1:
+        pad = torch.empty((37 << 20) + i * 4096, dtype=torch.uint8, device="cuda")   # shift the next allocation
+for rep in range(1):
+    for i, e in enumerate(engines):
+        for _ in range(10):
+            e.sort_from(keys.data_ptr(), n)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(40):
+            e.sort_from(keys.data_ptr(), n)
+        torch.cuda.synchronize()
+        print(f"rep {rep} engine {i}: {(time.perf_counter() - t0) / 40 * 1e3:.3f} ms per sort  result at {e.result_device()[0]:#x}", flush=True)
