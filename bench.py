@@ -30,6 +30,9 @@ with a host sort of all the inputs.
 RSX_BENCH_REHEARSAL=1 (tests only) swaps the device side for the CPU test double of
 tests/_bench_rehearsal.py under gloo, so that the launcher and every line of the N>1 rank
 logic can be run on a machine without GPUs; its line says so and carries no value.
+RSX_BENCH_SHARED_GPU=1 (tests only) keeps the real engine but puts every rank process on
+cuda:0 with gloo collectives staged through the host (tests/_host_staged_dist.py): the
+one-GPU test box's rehearsal of N rank processes; its line says so and carries no value too.
 """
 from __future__ import annotations
 
@@ -166,6 +169,7 @@ def main() -> None:
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}, or let bench.py start the ranks itself")
     rehearsal = os.environ.get("RSX_BENCH_REHEARSAL", "0") == "1"       # tests only: CPU test double under gloo
+    shared_gpu = os.environ.get("RSX_BENCH_SHARED_GPU", "0") == "1"     # tests only: every rank a process of its own on cuda:0, gloo staged through the host
     force_exchange = os.environ.get("RSX_FORCE_EXCHANGE", "0") == "1"   # 1 rank, but through RCCL
     sharded = world > 1 or force_exchange
     dist = None
@@ -175,6 +179,8 @@ def main() -> None:
         device = torch.device("cpu")
         sync = lambda: None     # noqa: E731
     else:
+        if shared_gpu:
+            local_rank = 0
         device = torch.device("cuda", local_rank)
         torch.cuda.set_device(device)
         sync = torch.cuda.synchronize
@@ -184,6 +190,11 @@ def main() -> None:
         os.environ.setdefault("MASTER_PORT", str(free_port()))
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+        elif shared_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from _host_staged_dist import HostStagedDist
+            dist = HostStagedDist()
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
@@ -396,6 +407,10 @@ def main() -> None:
         line["cpu_baseline"] = base_entry
     if rehearsal:
         line["metric"] = "REHEARSAL on a CPU test double (tests only) — not a measurement; " + METRIC
+        line["value"] = None
+        line["rehearsal"] = True
+    elif shared_gpu:
+        line["metric"] = "REHEARSAL: all ranks share ONE GPU, collectives staged through the host over gloo (tests only) — not a measurement; " + METRIC
         line["value"] = None
         line["rehearsal"] = True
     if rank == 0:

@@ -362,3 +362,25 @@ def test_partition_count_then_scatter(rsx, oracle):
         assert np.array_equal(out.cpu().numpy(), keys[np.argsort(d, kind="stable")])
         with pytest.raises(rsx.RadixSortError):          # the table was consumed
             e.partition_scatter(tk.data_ptr(), n, 28, 4, out.data_ptr())
+
+
+# --------------------------------------------------------------------------- real processes, one rank each, sharing the one GPU
+@pytest.mark.parametrize("ranks,extra,env", [
+    (2, ["--total-log2-keys", "23"], {}),
+    (4, ["--total-log2-keys", "24", "--cpu-sample-log2", "20"], {}),
+    (4, ["--total-log2-keys", "22", "--dtype", "int64", "--payload", "--dataset", "Zeros", "--no-cpu-baseline"], {}),
+    (3, ["--log2-keys", "20", "--dtype", "uint64", "--no-cpu-baseline"], {"RSX_STRATEGY": "split"}),
+    (4, ["--total-log2-keys", "22", "--dtype", "int32", "--dataset", "InvertedRange", "--no-cpu-baseline", "--radix-bits", "8"], {"RSX_STRATEGY": "range"}),
+])
+def test_bench_ranks_as_processes_on_the_shared_gpu(ranks, extra, env):
+    """`python bench.py --gpus N` as the driver runs it — bench.py starts N rank PROCESSES through torch.distributed.run,
+    each with its own HIP engine, streams and ShardedSorter — except that all ranks sit on cuda:0 and the collectives
+    are gloo staged through the host (tests/_host_staged_dist.py): RCCL will not put two ranks on one device.  Rank 0
+    gathers every rank's output and compares the concatenation with a host sort of all the inputs."""
+    line = _bench(["--gpus", str(ranks), "--steps", "2", "--warmup", "1"] + extra, dict(env, RSX_BENCH_SHARED_GPU="1"))
+    assert line["n_gpus"] == ranks and line["rehearsal"] is True and line["value"] is None
+    assert line["config"]["verified"].startswith("bit-exact vs a host sort of all")
+    assert f"x{ranks}" in line["config"]["parallelism"]
+    want_path = {"split": "split", "range": "range"}.get(env.get("RSX_STRATEGY"), "split" if "Zeros" in extra else "waves")
+    assert f"[{want_path}]" in line["config"]["parallelism"], line["config"]["parallelism"]
+    assert line["roofline"]["avg_launch_ms"] > 0
