@@ -84,6 +84,7 @@ typedef enum rsx_option {
     RSX_OPT_SMALL_TILE_MAX_KEYS = 12, /* (default 2^17) self-scan sorts of at most this many keys (<= 2^20) run on tiles of 1024 keys (4 per thread) instead of
                                  4096: a shorter per-tile dependency chain for latency-bound small sorts.  The engine's own table
                                  read-back is not produced in that geometry (the reference-geometry diagnostics are). */
+    RSX_OPT_SELF_SCAN_MAX_TILES = 14, /* (default 1024) largest table, in tiles (<= 1024), that takes the SELF_SCAN path */
     RSX_OPT_XCD_PHASE = 13,   /* (default -1) with XCD_REMAP: XCD x enters its tile range x * value tiles in and wraps round, so that the eight
                                  XCDs do not walk ranges that start n/8 apart in lockstep (same HBM channels); -1 = an eighth of a
                                  range, 0 = lockstep.  Placement only: results are identical. */

@@ -1151,6 +1151,10 @@ int rsx_set_option(rsx_engine* e, int option, int64_t value)
         if (value < 0) return fail(RSX_CALCULATION_FAILED, "rsx_set_option: negative key count");
         e->small_tile_max_keys = std::min<uint64_t>(static_cast<uint64_t>(value), static_cast<uint64_t>(rsx::kSelfScanMaxTiles) * kTileThreads * kSmallKeysPerThread);
         return RSX_OK;
+    case RSX_OPT_SELF_SCAN_MAX_TILES:
+        if (value < 0) return fail(RSX_CALCULATION_FAILED, "rsx_set_option: negative tile count");
+        e->self_scan_max = static_cast<uint32_t>(std::min<int64_t>(value, rsx::kSelfScanMaxTiles));
+        return RSX_OK;
     case RSX_OPT_XCD_PHASE:
         if (value < -1 || value > (1 << 22)) return fail(RSX_CALCULATION_FAILED, "rsx_set_option: XCD phase out of range");
         e->xcd_phase = value;

@@ -600,6 +600,27 @@ def test_small_tiles_sort_the_same(mod, oracle, dt, payload, n):
         assert np.array_equal(got, want_sorted) and np.array_equal(table, want_table) and np.array_equal(gs, want_gs)
 
 
+def test_self_scan_tile_limit_option(mod, oracle):
+    """RSX_OPT_SELF_SCAN_MAX_TILES moves the border between the self-scan chain and the chain with scan launches
+    (clamped to 1024 tiles): same keys and table on either side of it."""
+    n = (1 << 20) + 77
+    keys = oracle.dataset("SeededUniform", "uint32", n, seed=5)
+    seen = []
+    for limit in (64, 1 << 20):
+        with mod.Engine("uint32", n) as e:
+            e.set_option(mod.OPT_SELF_SCAN_MAX_TILES, limit)
+            e.set_option(mod.OPT_SMALL_TILE_MAX_KEYS, 0)
+            e.upload(keys)
+            e.sort()
+            seen.append(e.download(hist_cap=int(e.geometry().table_len)))
+    assert np.array_equal(seen[0][0], np.sort(keys))
+    for a, b in zip(seen[0], seen[1]):
+        assert np.array_equal(a, b)
+    with mod.Engine("uint32", 4096) as e:
+        with pytest.raises(mod.RadixSortError):
+            e.set_option(mod.OPT_SELF_SCAN_MAX_TILES, -1)
+
+
 # --------------------------------------------------------------------------- XCD phase stagger (placement only)
 @pytest.mark.parametrize("bits", [4, 8])
 @pytest.mark.parametrize("dt,payload", [("uint32", False), ("int64", True)])
