@@ -81,7 +81,7 @@ typedef enum rsx_option {
     RSX_OPT_SELF_SCAN = 11,   /* 1 (default): inside rsx_sort, tables of 2..1024 tiles (up to 2^22 keys) get no scan launch: every reorder
                                  workgroup derives the 16 first slots of its tile from the raw [tile][16] counts itself while
                                  its keys are on their way (passes + 1 dependent launches instead of 2 passes + 2) */
-    RSX_OPT_SMALL_TILE_MAX_KEYS = 12, /* (default 2^17) self-scan sorts of at most this many keys (<= 2^20) run on tiles of 1024 keys (4 per thread) instead of
+    RSX_OPT_SMALL_TILE_MAX_KEYS = 12, /* (default 2^19) self-scan sorts of at most this many keys (<= 2^20) run on tiles of 1024 keys (4 per thread) instead of
                                  4096: a shorter per-tile dependency chain for latency-bound small sorts.  The engine's own table
                                  read-back is not produced in that geometry (the reference-geometry diagnostics are). */
     RSX_OPT_SELF_SCAN_MAX_TILES = 14, /* (default 1024) largest table, in tiles (<= 1024), that takes the SELF_SCAN path */

@@ -183,7 +183,7 @@ struct rsx_engine {
     int self_scan = 1;          // rsx_sort: tables of at most self_scan_max tiles need no scan launch (env RSX_SELF_SCAN)
     uint32_t self_scan_max = 1024;              // env RSX_SELF_SCAN_MAX (<= 1024 tiles = 2^22 keys; measured: -36 % at 2^13..2^18, -24 % at 2^20, -11 % at 2^22)
     uint32_t* cnt3[3] = {nullptr, nullptr, nullptr};      // self-scan: three rotating [tile][16] count buffers
-    uint64_t small_tile_max_keys = 1u << 17;              // self-scan sorts of at most this many keys use tiles of 256 x 4 keys (env RSX_SMALL_TILE_MAX_KEYS; measured: -20 % up to 2^16, -4 % at 2^18, slower from 2^19)
+    uint64_t small_tile_max_keys = 1u << 19;              // self-scan sorts of at most this many keys use tiles of 256 x 4 keys (env RSX_SMALL_TILE_MAX_KEYS; measured: -20 % up to 2^16, -16 % at 2^18, -6 % at 2^19, +20 % at 2^20)
     int tile_sort = 1;          // rsx_sort: inputs of at most one tile are sorted by ONE workgroup in ONE launch, all passes in LDS (env RSX_TILE_SORT)
     int fold_paste = 0;         // reorder adds globsum itself (no paste launch): measured 3 % slower, off; env RSX_FOLD_PASTE
     int scan_zeroes = 1;

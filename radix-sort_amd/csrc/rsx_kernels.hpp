@@ -1059,34 +1059,57 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
 
     if (self_scan) {
         // (the key loads above are in flight; this is L2-resident table work under their latency)
-        const uint32_t d = tid & 15u, p = tid >> 4;
-        uint32_t tot = 0, pre = 0;
-        uint32_t t2 = p;
-        for (; t2 + 3 * (THREADS / kRadix) < ntiles; t2 += 4 * (THREADS / kRadix)) {
-            uint32_t v[4];
+        // thread (q = tid & 3, r = tid >> 2) reads digits 4q..4q+3 of the rows r, r + 64, ... with 16-byte loads: a wave covers
+        // 16 rows per instruction and a table of 1024 tiles is 4 rounds of 4 loads in flight
+        const uint32_t q = tid & 3u, r = tid >> 2;
+        constexpr uint32_t RS = THREADS / 4;
+        const U32x4* rows = reinterpret_cast<const U32x4*>(self.counts);
+        uint32_t tot[4] = {0u, 0u, 0u, 0u}, pre[4] = {0u, 0u, 0u, 0u};
+        uint32_t t2 = r;
+        for (; t2 + 3u * RS < ntiles; t2 += 4u * RS) {
+            U32x4 v[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                v[u] = self.counts[(t2 + static_cast<uint32_t>(u) * (THREADS / kRadix)) * kRadix + d];
+                v[u] = rows[(t2 + static_cast<uint32_t>(u) * RS) * 4u + q];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                tot += v[u];
-                pre += (t2 + static_cast<uint32_t>(u) * (THREADS / kRadix) < tile) ? v[u] : 0u;
+                const bool earlier = t2 + static_cast<uint32_t>(u) * RS < tile;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    tot[c] += v[u].v[c];
+                    pre[c] += earlier ? v[u].v[c] : 0u;
+                }
             }
         }
-        for (; t2 < ntiles; t2 += THREADS / kRadix) {
-            const uint32_t v = self.counts[t2 * kRadix + d];
-            tot += v;
-            pre += (t2 < tile) ? v : 0u;
+        for (; t2 < ntiles; t2 += RS) {
+            const U32x4 v = rows[t2 * 4u + q];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                tot[c] += v.v[c];
+                pre[c] += (t2 < tile) ? v.v[c] : 0u;
+            }
         }
-        tot += __shfl_xor(tot, 16);
-        pre += __shfl_xor(pre, 16);
-        tot += __shfl_xor(tot, 32);
-        pre += __shfl_xor(pre, 32);
+        // the 16 lanes of a wave with the same q: lanes q, q+4, q+8, q+12 of each row of 16 (row_ror:4, row_ror:8), then the four rows
+        auto same_q_sum = [](uint32_t x) -> uint32_t {
+            x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x124, 0xf, 0xf, false));
+            x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x128, 0xf, 0xf, false));
+            x += __shfl_xor(x, 16);
+            x += __shfl_xor(x, 32);
+            return x;
+        };
         const uint32_t lane = tid & (kWave - 1), wave = tid / kWave;
-        if (lane < kRadix) {
-            self_part[(wave * 2 + 0) * kRadix + lane] = tot;
-            self_part[(wave * 2 + 1) * kRadix + lane] = pre;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            tot[c] = same_q_sum(tot[c]);
+            pre[c] = same_q_sum(pre[c]);
+        }
+        if (lane < 4u) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                self_part[(wave * 2 + 0) * kRadix + lane * 4u + static_cast<uint32_t>(c)] = tot[c];
+                self_part[(wave * 2 + 1) * kRadix + lane * 4u + static_cast<uint32_t>(c)] = pre[c];
+            }
         }
         __syncthreads();
         if (tid < kRadix) {
