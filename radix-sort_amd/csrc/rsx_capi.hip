@@ -175,6 +175,7 @@ struct rsx_engine {
     int small_scan = 1;         // rsx_sort: one-workgroup scan+paste for tables of <= 1024 tiles (env RSX_SMALL_SCAN)
     uint64_t radix8_min_keys = 1u << 19;        // 8-bit passes only above this many keys (env RSX_RADIX8_MIN_KEYS; at least one tile)
     int radix_bits = 4;         // RSX_OPT_RADIX_BITS: 4 (the reference's configuration) or 8 (half the passes; rsx_sort chain only)
+    bool radix8_ready = false;                  // the five tables below exist and the reorder8 kernels may use their LDS
     uint32_t* counts8 = nullptr;                // 8-bit digits: raw counts [tile][256] (allocated on first use)
     uint32_t* table8 = nullptr;                 //   group-local exclusive prefixes [tile][256]
     uint32_t* gsum8 = nullptr;                  //   per scan group: totals, then prefixes inside the group's chunk [group][256]
@@ -617,18 +618,20 @@ int sort8_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext
     const uint32_t ngroups = (g.ntiles + rsx::kScan8Tiles - 1) / rsx::kScan8Tiles;
     const uint32_t chunk_groups = std::max<uint32_t>(64u, (ngroups + rsx::kScan8MaxChunks - 1) / rsx::kScan8MaxChunks);
     const uint32_t nchunks = (ngroups + chunk_groups - 1) / chunk_groups;
-    if (!e->counts8) {
+    if (!e->radix8_ready) {
+        // (allocated on first use; a call that failed half-way keeps what it got and the next one asks for the rest)
         const size_t rows = static_cast<size_t>(e->ntiles(e->capacity)) * rsx::kRadix8 * 4;
         const size_t groups = ((e->ntiles(e->capacity) + rsx::kScan8Tiles - 1) / rsx::kScan8Tiles) * rsx::kRadix8 * 4;
-        RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->counts8), rows), RSX_INITIALIZATION_FAILED);
-        RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->table8), rows), RSX_INITIALIZATION_FAILED);
-        RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->gsum8), groups), RSX_INITIALIZATION_FAILED);
-        RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->csum8), rsx::kScan8MaxChunks * rsx::kRadix8 * 4), RSX_INITIALIZATION_FAILED);
-        RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->cbase8), rsx::kScan8MaxChunks * rsx::kRadix8 * 4), RSX_INITIALIZATION_FAILED);
+        if (!e->counts8) RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->counts8), rows), RSX_INITIALIZATION_FAILED);
+        if (!e->table8) RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->table8), rows), RSX_INITIALIZATION_FAILED);
+        if (!e->gsum8) RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->gsum8), groups), RSX_INITIALIZATION_FAILED);
+        if (!e->csum8) RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->csum8), rsx::kScan8MaxChunks * rsx::kRadix8 * 4), RSX_INITIALIZATION_FAILED);
+        if (!e->cbase8) RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->cbase8), rsx::kScan8MaxChunks * rsx::kRadix8 * 4), RSX_INITIALIZATION_FAILED);
         RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L::BYTES)), RSX_INITIALIZATION_FAILED);
         RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L::BYTES)), RSX_INITIALIZATION_FAILED);
+        e->radix8_ready = true;
     }
     const void* in = ext_keys ? ext_keys : e->keys[e->cur];
     const uint32_t* pin = e->has_payload ? (ext_keys ? ext_perm : e->perm[e->cur]) : nullptr;
@@ -1330,20 +1333,21 @@ int pipeline_init(rsx_engine* e)
 {
     rsx_engine::Pipeline& p = e->pipe;
     if (p.ready) return RSX_OK;
+    // (a call that failed half-way keeps what it got — rsx_destroy frees it — and the next one asks only for the rest)
     const size_t key_buf = static_cast<size_t>(e->capacity) * e->key_bytes;
     for (int i = 0; i < 2; ++i) {
-        RSX_TRY(hipMalloc(&p.in[i], key_buf), RSX_INITIALIZATION_FAILED);
-        RSX_TRY(hipMalloc(&p.out[i], key_buf), RSX_INITIALIZATION_FAILED);
+        if (!p.in[i]) RSX_TRY(hipMalloc(&p.in[i], key_buf), RSX_INITIALIZATION_FAILED);
+        if (!p.out[i]) RSX_TRY(hipMalloc(&p.out[i], key_buf), RSX_INITIALIZATION_FAILED);
         if (e->has_payload) {
-            RSX_TRY(hipMalloc(reinterpret_cast<void**>(&p.pin[i]), static_cast<size_t>(e->capacity) * 4), RSX_INITIALIZATION_FAILED);
-            RSX_TRY(hipMalloc(reinterpret_cast<void**>(&p.pout[i]), static_cast<size_t>(e->capacity) * 4), RSX_INITIALIZATION_FAILED);
+            if (!p.pin[i]) RSX_TRY(hipMalloc(reinterpret_cast<void**>(&p.pin[i]), static_cast<size_t>(e->capacity) * 4), RSX_INITIALIZATION_FAILED);
+            if (!p.pout[i]) RSX_TRY(hipMalloc(reinterpret_cast<void**>(&p.pout[i]), static_cast<size_t>(e->capacity) * 4), RSX_INITIALIZATION_FAILED);
         }
-        RSX_TRY(hipEventCreateWithFlags(&p.in_ready[i], hipEventDisableTiming), RSX_INITIALIZATION_FAILED);
-        RSX_TRY(hipEventCreateWithFlags(&p.sorted[i], hipEventDisableTiming), RSX_INITIALIZATION_FAILED);
-        RSX_TRY(hipEventCreateWithFlags(&p.out_done[i], hipEventDisableTiming), RSX_INITIALIZATION_FAILED);
+        if (!p.in_ready[i]) RSX_TRY(hipEventCreateWithFlags(&p.in_ready[i], hipEventDisableTiming), RSX_INITIALIZATION_FAILED);
+        if (!p.sorted[i]) RSX_TRY(hipEventCreateWithFlags(&p.sorted[i], hipEventDisableTiming), RSX_INITIALIZATION_FAILED);
+        if (!p.out_done[i]) RSX_TRY(hipEventCreateWithFlags(&p.out_done[i], hipEventDisableTiming), RSX_INITIALIZATION_FAILED);
     }
-    RSX_TRY(hipStreamCreateWithFlags(&p.s_in, hipStreamNonBlocking), RSX_INITIALIZATION_FAILED);
-    RSX_TRY(hipStreamCreateWithFlags(&p.s_out, hipStreamNonBlocking), RSX_INITIALIZATION_FAILED);
+    if (!p.s_in) RSX_TRY(hipStreamCreateWithFlags(&p.s_in, hipStreamNonBlocking), RSX_INITIALIZATION_FAILED);
+    if (!p.s_out) RSX_TRY(hipStreamCreateWithFlags(&p.s_out, hipStreamNonBlocking), RSX_INITIALIZATION_FAILED);
     p.ready = true;
     return RSX_OK;
 }
