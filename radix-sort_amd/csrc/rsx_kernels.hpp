@@ -54,6 +54,24 @@ struct alignas(16) U32x4 {
     uint32_t v[4];
 };
 
+// Keys are read exactly once per pass: RSX_STREAM_LOADS=1 marks those 16-byte loads non-temporal (experiment, tuning log §7).
+#ifndef RSX_STREAM_LOADS
+#define RSX_STREAM_LOADS 0
+#endif
+template <typename Key>
+__device__ __forceinline__ KeyVec<Key> load_keys16(const Key* p)
+{
+#if RSX_STREAM_LOADS
+    typedef uint32_t u32x4_native __attribute__((ext_vector_type(4)));
+    const u32x4_native x = __builtin_nontemporal_load(reinterpret_cast<const u32x4_native*>(p));
+    KeyVec<Key> v;
+    __builtin_memcpy(&v, &x, 16);
+    return v;
+#else
+    return *reinterpret_cast<const KeyVec<Key>*>(p);
+#endif
+}
+
 // The packed counters in LDS are touched as 16-bit halves, 32-bit words and 16-byte
 // vectors; these typedefs keep type-based alias analysis from reordering them.
 typedef uint16_t __attribute__((may_alias)) u16_alias;
@@ -231,7 +249,7 @@ __global__ __launch_bounds__(THREADS) void histogram_kernel(const Key* __restric
         KeyVec<Key> v[NV];
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            v[j] = *reinterpret_cast<const KeyVec<Key>*>(keys + base + static_cast<uint32_t>(j) * THREADS * VEC + tid * VEC);
+            v[j] = load_keys16(keys + base + static_cast<uint32_t>(j) * THREADS * VEC + tid * VEC);
         }
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
@@ -1023,7 +1041,7 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
     if (full) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const KeyVec<Key> v = *reinterpret_cast<const KeyVec<Key>*>(in + base + tid * KPT + j * VEC);
+            const KeyVec<Key> v = load_keys16(in + base + tid * KPT + j * VEC);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 k[j * VEC + e] = v.k[e];
@@ -1650,7 +1668,7 @@ __global__ __launch_bounds__(THREADS) void histogram8_kernel(const Key* __restri
         KeyVec<Key> v[NV];
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            v[j] = *reinterpret_cast<const KeyVec<Key>*>(keys + base + static_cast<uint32_t>(j) * THREADS * VEC + tid * VEC);
+            v[j] = load_keys16(keys + base + static_cast<uint32_t>(j) * THREADS * VEC + tid * VEC);
         }
         // a wave whose keys all share the digit (constant or sorted data) would serialise 64 lanes on one LDS
         // address per key: the first key stands for the wave, as in reorder_kernel's look-ahead
@@ -1850,7 +1868,7 @@ __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREAD
     if (full) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const KeyVec<Key> v = *reinterpret_cast<const KeyVec<Key>*>(in + base + tid * KPT + j * VEC);
+            const KeyVec<Key> v = load_keys16(in + base + tid * KPT + j * VEC);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 k[j * VEC + e] = v.k[e];
