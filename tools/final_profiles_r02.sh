@@ -31,6 +31,10 @@ pmc c5inv   "2^28 uint32 InvertedRange, 4-bit digits, 8 passes" --dataset Invert
 pmc c5uni   "2^28 uint32 RandomDistributed, 4-bit digits, 8 passes" --dataset RandomDistributed || exit 3
 pmc c2r8    "2^28 uint32 Random, 8-bit digits, 4 passes" --radix-bits 8 || exit 3
 cd $R
+#  5. SQ counters of the same workload (two separate --pmc passes, no tracing): how busy the VALU / LDS pipes are
+bash tools/pmc_sq.sh final > $O/sq_counters.txt 2>&1 || exit 5
+rm -rf $R/gpurun_out/sq_final_a $R/gpurun_out/sq_final_b
+echo "sq counters done"
 bash tools/run_matrix.sh $O/matrix.jsonl > $O/matrix.txt 2>&1
 sed 's/python bench.py/python bench.py --radix-bits 8/' tools/run_matrix.sh > /tmp/run_matrix8.sh && bash /tmp/run_matrix8.sh $O/matrix_8bit.jsonl > $O/matrix_8bit.txt 2>&1
 echo "matrix done"
