@@ -12,7 +12,7 @@ import __graft_entry__ as entry
 m = entry.load_package()
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
-cap = 3_000_000
+cap = int(os.environ.get("RSX_SOAK_CAP", 9_000_000))      # 2,197 tiles: both sides of the self-scan / fused-scan border
 engines = {(dt, p): m.Engine(dt, cap, payload=p) for dt in ("uint32", "int32", "uint64", "int64") for p in (False, True)}
 t0 = time.time()
 for it in range(iters):
@@ -34,6 +34,14 @@ for it in range(iters):
     e = engines[(dt, payload)]
     e.set_option(m.OPT_LOOKAHEAD, int(rng.integers(0, 2)))
     e.set_option(m.OPT_SMALL_SCAN, int(rng.integers(0, 2)))
+    # every path of the chain dispatch, in any combination (all of them must give the same array)
+    e.set_option(m.OPT_RADIX_BITS, (4, 4, 8)[rng.integers(0, 3)])
+    e.set_option(m.OPT_SELF_SCAN, int(rng.integers(0, 4) != 0))
+    e.set_option(m.OPT_FUSED_SCAN, int(rng.integers(0, 4) != 0))
+    e.set_option(m.OPT_TILE_SORT, int(rng.integers(0, 4) != 0))
+    e.set_option(m.OPT_XCD_PHASE, (-1, 0, int(rng.integers(1, 40)))[rng.integers(0, 3)])
+    e.set_option(m.OPT_SMALL_TILE_MAX_KEYS, (1 << 19, 0, 1 << 20)[rng.integers(0, 3)])
+    e.set_option(m.OPT_SELF_SCAN_MAX_TILES, (1024, 1024, 100)[rng.integers(0, 3)])
     perm = np.arange(n, dtype=np.uint32) if payload else None
     e.upload(keys, perm)
     e.sort()
