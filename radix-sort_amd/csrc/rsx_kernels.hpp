@@ -792,28 +792,36 @@ struct alignas(8) RunBase {
 // wave targets ONE counter (constant or sorted data: every pass of Zeros, most passes of
 // Range) the uniform branch lets lane 0 add 64 instead of 64 lanes serialising on one address.
 constexpr uint32_t kLaDummy = 2 * kRadix * kRadix;   // one spare counter past the 512 real ones
-// Optional (-DRSX_LA_REPLICAS=2): every counter in two adjacent copies, odd and even lanes adding to different ones, so that the 32
-// lanes of one LDS pass hit 32 different words instead of piling two deep on 16 addresses.  Measured in both rounds: no difference
-// at steady state (3.607-3.613 ms per sort either way) — SQ counters put the look-ahead adds at 37 % of the fused kernel's LDS
-// cycles, but at full clock the kernel waits for HBM, not for LDS.  One copy is the default (less LDS).
+// RSX_LA_REPLICAS=2 (default): every counter in two adjacent copies, odd and even lanes adding to different ones, so that the 32
+// lanes of one LDS pass hit 32 different words instead of piling two deep on 16 addresses.  Before the XCD stagger this made no
+// difference (the kernel waited for HBM); with it, interleaved A/B: 3.345-3.392 against 3.369-3.423 ms per sort back to back,
+// and 0.417-0.424 against 0.430-0.447 ms per scatter launch right after an upload, when the shader clock is low and the waves
+// wait for LDS issue (SQ counters: 23 % of their cycles, bank conflicts on 49 % of the LDS cycles with one copy).
 #ifndef RSX_EARLY_RANK
 #define RSX_EARLY_RANK 1
 #endif
 #ifndef RSX_LA_REPLICAS
-#define RSX_LA_REPLICAS 1
+#define RSX_LA_REPLICAS 2
 #endif
 constexpr int kLaReplicas = RSX_LA_REPLICAS;
 static_assert(kLaReplicas == 1 || kLaReplicas == 2, "odd/even-lane replicas");
 
+// (the payload kernels keep one copy: their A/B showed nothing beyond run-to-run noise, and they are the ones short of registers)
+template <bool PAYLOAD>
+constexpr int la_replicas()
+{
+    return PAYLOAD ? 1 : kLaReplicas;
+}
+template <int REPL>
 __device__ __forceinline__ void lookahead_count(uint32_t* la, uint32_t idx)
 {
     const uint32_t first = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(idx)));
     if (__builtin_expect(__ballot(idx != first) == 0ull, 0)) {
         if ((threadIdx.x & (kWave - 1)) == 0) {
-            atomicAdd(&la[first * kLaReplicas], static_cast<uint32_t>(kWave));
+            atomicAdd(&la[first * REPL], static_cast<uint32_t>(kWave));
         }
     } else {
-        atomicAdd(&la[idx * kLaReplicas + (threadIdx.x & (kLaReplicas - 1))], 1u);
+        atomicAdd(&la[idx * REPL + (threadIdx.x & (REPL - 1))], 1u);
     }
 }
 
@@ -1361,15 +1369,16 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
         // digits) the other rounds simply add; otherwise every round is tested.
         const uint32_t first0 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(la_idx[0])));
         if (__builtin_expect(__ballot(la_idx[0] != first0) != 0ull, 1)) {
-            uint32_t* la_mine = la + (tid & (kLaReplicas - 1));      // this lane's copy of every counter
+            constexpr int REPL = la_replicas<PAYLOAD>();
+            uint32_t* la_mine = la + (tid & (REPL - 1));             // this lane's copy of every counter
 #pragma unroll
             for (int r = 0; r < KPT; ++r) {
-                atomicAdd(&la_mine[la_idx[r] * kLaReplicas], 1u);
+                atomicAdd(&la_mine[la_idx[r] * REPL], 1u);
             }
         } else {
 #pragma unroll
             for (int r = 0; r < KPT; ++r) {
-                lookahead_count(la, la_idx[r]);
+                lookahead_count<la_replicas<PAYLOAD>()>(la, la_idx[r]);
             }
         }
     }
@@ -1404,9 +1413,10 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
         uint32_t first = tid;
         asm volatile("" : "+v"(first));
         for (uint32_t c = first; c < kLaDummy; c += THREADS) {
-            uint32_t v = la[c * kLaReplicas];
-            if constexpr (kLaReplicas == 2) {
-                v += la[c * kLaReplicas + 1];
+            constexpr int REPL = la_replicas<PAYLOAD>();
+            uint32_t v = la[c * REPL];
+            if constexpr (REPL == 2) {
+                v += la[c * REPL + 1];
             }
             if (v) {
                 // counter c = [raw digit d][segment][raw next digit]; the counts table is indexed by the TRUE next digit

@@ -15,9 +15,11 @@ n = 1 << 28
 keys = torch.from_numpy(np.random.default_rng(1).integers(0, 2**32, size=n, dtype=np.uint32).view(np.int32)).cuda()
 stream = torch.cuda.Stream()
 torch.cuda.set_stream(stream)
+payload = os.environ.get("MODE_PAYLOAD", "0") == "1"
+perm = torch.arange(n, dtype=torch.int32, device="cuda") if payload else None
 engines = []
-for i in range(5):
-    e = m.Engine("uint32", n)
+for i in range(int(os.environ.get("MODE_ENGINES", "5"))):
+    e = m.Engine("uint32", n, payload=payload)
     e.set_stream(stream.cuda_stream)
     engines.append(e)
     if i % 2 == 1:
@@ -25,10 +27,10 @@ for i in range(5):
 for rep in range(1):
     for i, e in enumerate(engines):
         for _ in range(10):
-            e.sort_from(keys.data_ptr(), n)
+            e.sort_from(keys.data_ptr(), n, perm.data_ptr() if payload else None)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(40):
-            e.sort_from(keys.data_ptr(), n)
+            e.sort_from(keys.data_ptr(), n, perm.data_ptr() if payload else None)
         torch.cuda.synchronize()
         print(f"rep {rep} engine {i}: {(time.perf_counter() - t0) / 40 * 1e3:.3f} ms per sort  result at {e.result_device()[0]:#x}", flush=True)
