@@ -76,8 +76,10 @@ typedef enum rsx_option {
     RSX_OPT_RADIX_BITS = 10,  /* digit width of the rsx_sort chain: 4 (default, the reference's _NUM_BITS_PER_RADIX, src/Parameters.h:25) or 8.
                                  With 8 a pass sorts by a whole byte (two stable 4-bit rounds inside LDS, one scatter of up to
                                  256 runs per tile): half the passes over HBM.  Same result.  Pass ranges (RSX_OPT_FIRST_PASS /
-                                 LAST_PASS, rsx_sort_from_to) stay in units of 4-bit passes and must cover whole bytes, otherwise
-                                 the 4-bit chain runs; the step API and the diagnostic tables are those of 4-bit passes. */
+                                 LAST_PASS, rsx_sort_from_to) stay in units of 4-bit passes: a range of whole bytes runs 8-bit passes, an odd
+                                 range that starts on a byte boundary runs them for its whole bytes and one 4-bit pass for the last
+                                 nibble, any other range runs the 4-bit chain; the step API and the diagnostic tables are those of
+                                 4-bit passes. */
     RSX_OPT_SELF_SCAN = 11,   /* 1 (default): inside rsx_sort, tables of 2..1024 tiles (up to 2^22 keys) get no scan launch: every reorder
                                  workgroup derives the 16 first slots of its tile from the raw [tile][16] counts itself while
                                  its keys are on their way (passes + 1 dependent launches instead of 2 passes + 2) */

@@ -701,6 +701,25 @@ int sort_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext_
     if (e->radix_bits == 8 && count > e->radix8_min_keys && e->first_pass < e->last_pass && (e->first_pass & 1) == 0 && (e->last_pass & 1) == 0) {
         return sort8_chain_enqueue<Key>(e, ext_keys, ext_perm, count);
     }
+    if (e->radix_bits == 8 && count > e->radix8_min_keys && (e->first_pass & 1) == 0 && (e->last_pass & 1) == 1 && e->last_pass - e->first_pass >= 3) {
+        // an odd range from a byte boundary (the sharded sort's local passes 0 .. P-2): whole bytes with 8-bit digits inside the
+        // engine's buffers, then the last nibble as one 4-bit pass into wherever the result was asked for
+        const int first = e->first_pass, last = e->last_pass;
+        void* const keys_out = e->final_keys_out;
+        uint32_t* const perm_out = e->final_perm_out;
+        e->last_pass = last - 1;
+        e->final_keys_out = nullptr;
+        e->final_perm_out = nullptr;
+        int rc = sort8_chain_enqueue<Key>(e, ext_keys, ext_perm, count);
+        e->last_pass = last;
+        e->final_keys_out = keys_out;
+        e->final_perm_out = perm_out;
+        if (rc != RSX_OK) return rc;
+        e->first_pass = last - 1;
+        rc = sort_chain_enqueue<Key>(e, nullptr, nullptr, count);
+        e->first_pass = first;
+        return rc;
+    }
     if (e->tile_sort && e->profile != 1 && count > 0 && count <= static_cast<uint64_t>(kTileKeys) && e->first_pass < e->last_pass) {
         return sort_tile_enqueue<Key>(e, ext_keys, ext_perm, count);
     }

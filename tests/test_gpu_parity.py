@@ -487,7 +487,9 @@ def test_8bit_digits_pass_ranges_external_buffers_and_golden(mod, oracle, golden
     with mod.Engine("int64", n, payload=True) as e:
         e.set_stream(torch.cuda.current_stream().cuda_stream)
         e.set_option(mod.OPT_RADIX_BITS, 8)
-        for first, last in ((0, 16), (0, 14), (2, 8), (1, 16), (0, 5)):      # whole bytes -> 8-bit passes; otherwise the 4-bit chain
+        # whole bytes -> 8-bit passes; an odd range from a byte boundary -> 8-bit passes + one 4-bit pass for the last nibble
+        # (the sharded sort's local passes 0 .. P-2); anything else -> the 4-bit chain
+        for first, last in ((0, 16), (0, 14), (2, 8), (1, 16), (0, 5), (0, 15), (2, 7), (0, 3), (4, 15), (0, 1)):
             out = torch.zeros(n + 5, dtype=t.dtype, device="cuda")
             pout = torch.zeros(n + 5, dtype=torch.int32, device="cuda")
             e.sort_from_to(t.data_ptr(), n, first, last, out[2:].data_ptr(), pay.data_ptr(), pout[2:].data_ptr())

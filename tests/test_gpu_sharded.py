@@ -370,6 +370,7 @@ def test_partition_count_then_scatter(rsx, oracle):
     (4, ["--total-log2-keys", "24", "--cpu-sample-log2", "20"], {}),
     (4, ["--total-log2-keys", "22", "--dtype", "int64", "--payload", "--dataset", "Zeros", "--no-cpu-baseline"], {}),
     (3, ["--log2-keys", "20", "--dtype", "uint64", "--no-cpu-baseline"], {"RSX_STRATEGY": "split"}),
+    (2, ["--total-log2-keys", "23", "--radix-bits", "8", "--payload", "--no-cpu-baseline"], {}),      # waves: 7 local passes = 3 bytes + a nibble
     (4, ["--total-log2-keys", "22", "--dtype", "int32", "--dataset", "InvertedRange", "--no-cpu-baseline", "--radix-bits", "8"], {"RSX_STRATEGY": "range"}),
 ])
 def test_bench_ranks_as_processes_on_the_shared_gpu(ranks, extra, env):
