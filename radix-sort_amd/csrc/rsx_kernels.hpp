@@ -903,7 +903,10 @@ struct ReorderLayout {
     // __launch_bounds__ argument = waves per SIMD, not blocks per CU); never asked beyond 6 (80 VGPRs: what the keys-only
     // kernels need; 8 would mean 64 and spills).
     static constexpr int WGS_PER_CU = static_cast<int>((160 * 1024) / BYTES);
-    static constexpr int MIN_WAVES = (WGS_PER_CU * THREADS / 256) > 6 ? 6 : (WGS_PER_CU * THREADS / 256);
+#ifndef RSX_REORDER_WAVES_CAP
+#define RSX_REORDER_WAVES_CAP 6      // 7 (72 VGPRs) measured twice, before and after the XCD stagger: see the tuning log
+#endif
+    static constexpr int MIN_WAVES = (WGS_PER_CU * THREADS / 256) > RSX_REORDER_WAVES_CAP ? RSX_REORDER_WAVES_CAP : (WGS_PER_CU * THREADS / 256);
     static_assert(TILE <= 32768, "16-bit packed counters");
     static_assert(KPT % (16 / sizeof(Key)) == 0 && THREADS % 64 == 0 && THREADS % 8 == 0, "geometry");
 };
