@@ -264,6 +264,13 @@ int rsx_partition_range(rsx_engine* e, const void* d_keys, const uint32_t* d_pay
 int rsx_result_device(rsx_engine* e, void** d_keys, uint32_t** d_payload);
 int rsx_copy_result(rsx_engine* e, void* d_keys_out, uint32_t* d_payload_out);
 
+/* Launch geometry of the tile kernels, as host arithmetic (no device is touched): workgroup b of a launch over
+ * num_keys keys in tiles of tile_keys keys works on tile tiles_out[b] (values >= *ntiles mark workgroups that
+ * exit at once); *blocks = workgroups launched.  xcd_remap / xcd_phase as RSX_OPT_XCD_REMAP / RSX_OPT_XCD_PHASE.
+ * At most cap entries are written.  For tests of the mapping: every tile must appear exactly once. */
+int rsx_tile_map(uint64_t num_keys, uint32_t tile_keys, int xcd_remap, int64_t xcd_phase, uint32_t* tiles_out, uint64_t cap,
+                 uint32_t* blocks, uint32_t* ntiles);
+
 /* ---- measurements ------------------------------------------------------------
  * rsx_timings synchronises, folds pending HIP-event pairs into the statistics and
  * copies them out (getRuntimes, src/RadixSortGPU.cpp:591-595); reset != 0 clears

@@ -38,7 +38,7 @@ SYMBOLS = [
     "rsx_create", "rsx_destroy", "rsx_set_stream", "rsx_get_stream", "rsx_set_option", "rsx_get_geometry", "rsx_resize",
     "rsx_upload", "rsx_fill_pad", "rsx_download", "rsx_pin_host", "rsx_unpin_host", "rsx_pipeline_submit", "rsx_pipeline_wait", "rsx_host_device_pointer",
     "rsx_histogram", "rsx_scan", "rsx_paste", "rsx_reorder", "rsx_sort", "rsx_sync",
-    "rsx_sort_from", "rsx_partition", "rsx_partition_count", "rsx_partition_scatter", "rsx_sample_keys", "rsx_partition_count_split", "rsx_partition_scatter_split", "rsx_partition_count_waves", "rsx_partition_scatter_waves", "rsx_sort_from_to", "rsx_key_range", "rsx_partition_range", "rsx_result_device", "rsx_copy_result", "rsx_timings",
+    "rsx_sort_from", "rsx_partition", "rsx_partition_count", "rsx_partition_scatter", "rsx_sample_keys", "rsx_partition_count_split", "rsx_partition_scatter_split", "rsx_partition_count_waves", "rsx_partition_scatter_waves", "rsx_sort_from_to", "rsx_key_range", "rsx_partition_range", "rsx_result_device", "rsx_copy_result", "rsx_tile_map", "rsx_timings",
 ]
 
 
@@ -143,6 +143,7 @@ def load_library() -> C.CDLL:
         "rsx_result_device": ([P, C.POINTER(P), C.POINTER(P)], I),
         "rsx_copy_result": ([P, P, P], I),
         "rsx_timings": ([P, C.POINTER(Runtimes), I], I),
+        "rsx_tile_map": ([C.c_uint64, C.c_uint32, I, C.c_int64, C.POINTER(C.c_uint32), C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)], I),
     }
     for name, (args, res) in sig.items():
         fn = getattr(lib, name)
@@ -378,6 +379,20 @@ class Engine:
         r = Runtimes()
         self._check(self.lib.rsx_timings(self._h, C.byref(r), int(reset)), "rsx_timings")
         return r
+
+
+def tile_map(num_keys: int, tile_keys: int = 4096, xcd_remap: bool = True, xcd_phase: int = -1) -> tuple[np.ndarray, int]:
+    """Tile of every workgroup of a launch over num_keys keys (rsx_tile_map: host arithmetic, no GPU) and the tile count."""
+    lib = load_library()
+    blocks, ntiles = C.c_uint32(0), C.c_uint32(0)
+    rc = lib.rsx_tile_map(num_keys, tile_keys, int(xcd_remap), xcd_phase, None, 0, C.byref(blocks), C.byref(ntiles))
+    if rc != 0:
+        raise RadixSortError(rc, "rsx_tile_map", lib.rsx_last_error().decode())
+    out = np.empty(blocks.value, dtype=np.uint32)
+    rc = lib.rsx_tile_map(num_keys, tile_keys, int(xcd_remap), xcd_phase, out.ctypes.data_as(C.POINTER(C.c_uint32)), out.size, C.byref(blocks), C.byref(ntiles))
+    if rc != 0:
+        raise RadixSortError(rc, "rsx_tile_map", lib.rsx_last_error().decode())
+    return out, ntiles.value
 
 
 def sort_host(keys: np.ndarray, payload: np.ndarray | None = None, device: int = 0):

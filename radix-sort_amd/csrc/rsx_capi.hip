@@ -1808,6 +1808,20 @@ int rsx_partition_range(rsx_engine* e, const void* d_keys, const uint32_t* d_pay
     return RSX_OK;
 }
 
+int rsx_tile_map(uint64_t num_keys, uint32_t tile_keys, int xcd_remap, int64_t xcd_phase, uint32_t* tiles_out, uint64_t cap, uint32_t* blocks, uint32_t* ntiles)
+{
+    if (!blocks || !ntiles || tile_keys == 0 || (cap > 0 && !tiles_out)) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_tile_map: null argument");
+    if (xcd_phase < -1 || (num_keys + tile_keys - 1) / tile_keys > (1ull << 24)) return fail(RSX_RESIZE_FAILED, "rsx_tile_map: out of range");
+    rsx_engine probe;                    // no device is touched: the launch geometry is host arithmetic
+    probe.xcd_remap = xcd_remap != 0;
+    probe.xcd_phase = xcd_phase;
+    const Grid g = grid_for(&probe, num_keys, tile_keys);
+    *blocks = g.blocks;
+    *ntiles = g.ntiles;
+    for (uint64_t b = 0; b < g.blocks && b < cap; ++b) tiles_out[b] = rsx::tile_of_block(static_cast<uint32_t>(b), g.tiles_per_xcd, g.remap);
+    return RSX_OK;
+}
+
 int rsx_result_device(rsx_engine* e, void** d_keys, uint32_t** d_payload)
 {
     if (!e) return fail(RSX_CALCULATION_FAILED, "rsx_result_device: null engine");

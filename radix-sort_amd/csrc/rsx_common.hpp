@@ -120,7 +120,7 @@ __device__ __forceinline__ uint32_t splitter_bucket(Key x, const SplitSet<Key>& 
 // eight XCDs advance in lockstep through ranges that start exactly n/8 apart (128 MiB at 2^28 uint32 keys), i.e. at any moment
 // their eight read streams (and the 8 x 16 write streams) sit on identical low address bits and pile onto the same HBM channels:
 // measured 3.57-3.69 ms per sort in lockstep against 3.34-3.40 ms staggered (profiles/r02_tuning_log.md §6).
-__device__ __forceinline__ uint32_t tile_of_block(uint32_t bid, uint32_t tiles_per_xcd, int remap)
+__host__ __device__ __forceinline__ uint32_t tile_of_block(uint32_t bid, uint32_t tiles_per_xcd, int remap)
 {
     if (!(remap & 1)) {
         return bid;

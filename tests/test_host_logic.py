@@ -120,3 +120,34 @@ def test_bench_rehearsal_eight_ranks_is_config_4_shaped():
     assert line["n_gpus"] == 8 and line["config"]["keys_per_gpu"] == 1 << 14 and line["scaling"] == "strong"
     assert "waves" in line["config"]["parallelism"] and "x8" in line["config"]["parallelism"]
     assert line["config"]["verified"].startswith("bit-exact vs a host sort of all 131072 keys")
+
+
+def test_xcd_tile_map_visits_every_tile_exactly_once(rsx):
+    """rsx_tile_map = the launch geometry of every tile kernel as host arithmetic (rsx::tile_of_block, grid_for): whatever
+    the key count, tile size and XCD phase, each tile has exactly one workgroup, surplus workgroups name tiles past the
+    end, and with the stagger XCD x (workgroup index mod 8) still walks one contiguous range, entered x * phase tiles in."""
+    import numpy as np
+    for n, tile_keys in ((1, 4096), (4096, 4096), (4097, 4096), (100003, 1024), (1 << 20, 1024), ((1 << 22) + 77, 4096),
+                         (2130003 * 4, 4096), (1 << 26, 4096), (1 << 28, 4096), (250_000_000, 4096)):
+        want_tiles = (n + tile_keys - 1) // tile_keys
+        for remap in (True, False):
+            for phase in (-1, 0, 1, 5, 1024, 1 << 20):
+                tiles, ntiles = rsx.tile_map(n, tile_keys, remap, phase)
+                assert ntiles == want_tiles
+                live = tiles[tiles < ntiles]
+                assert live.size == ntiles and np.array_equal(np.sort(live), np.arange(ntiles, dtype=np.uint32)), (n, tile_keys, remap, phase)
+                if not remap:
+                    assert np.array_equal(tiles, np.arange(ntiles, dtype=np.uint32))
+                    continue
+                per_xcd = (ntiles + 7) // 8
+                assert tiles.size == 8 * per_xcd
+                for x in range(8):
+                    mine = tiles[x::8].astype(np.int64)
+                    assert mine.min() >= x * per_xcd and mine.max() < (x + 1) * per_xcd       # its own contiguous range
+                    steps = np.diff(mine)
+                    assert np.count_nonzero(steps != 1) <= 1                                   # one wrap at most
+    # the default phase at the headline size: an eighth of a range
+    tiles, _ = rsx.tile_map(1 << 28)
+    assert [int(t) for t in tiles[:8]] == [x * 8192 + x * 1024 for x in range(8)]
+    with pytest.raises(rsx.RadixSortError):
+        rsx.tile_map(1 << 28, 4096, True, -2)
