@@ -210,7 +210,10 @@ int rsx_sync(rsx_engine* e);   /* CommandQueue.finish() */
  * rsx_partition: ONE stable radix pass on the bit field [shift, shift+bits) of
  *   external keys into caller-provided output buffers; bucket_offsets receives
  *   (1<<bits)+1 exclusive offsets.  This is the bucket-grouping step of the
- *   multi-GPU exchange.  Synchronises the stream before returning. */
+ *   multi-GPU exchange.  Synchronises the stream before returning.
+ *   All partition entry points read keys and payload 16 bytes per lane: d_keys and d_payload must be 16-byte
+ *   aligned (RSX_HOST_BUFFERS_FAILED otherwise); outputs need the alignment of their element type only,
+ *   except where stated. */
 /* Aliasing: d_keys may be the start of one of the engine's own two key buffers (the pointer
  * rsx_result_device returns; with a payload engine d_payload must then be the matching payload
  * buffer) — the sort then runs through the internal ping-pong, as rsx_sort does.  Any other overlap of

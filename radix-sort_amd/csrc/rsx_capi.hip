@@ -1227,13 +1227,13 @@ int rsx_upload(rsx_engine* e, const void* host_keys, const uint32_t* host_perm, 
     if (!e) return fail(RSX_DATA_UPLOAD_FAILED, "rsx_upload: null engine");
     if (n > e->capacity) return fail(RSX_DATA_UPLOAD_FAILED, "rsx_upload: beyond capacity");
     if (n > 0 && !host_keys) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_upload: null host keys");
+    if (n > 0 && e->has_payload && !host_perm) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_upload: payload engine needs a permutation buffer");
     if (bind_device(e, RSX_DATA_UPLOAD_FAILED) != RSX_OK) return RSX_DATA_UPLOAD_FAILED;
     e->n = n;
     if (n > 0) {
         RSX_TRY(hipMemcpyAsync(e->keys[e->cur], host_keys, static_cast<size_t>(n) * e->key_bytes, hipMemcpyHostToDevice, e->stream),
                 RSX_DATA_UPLOAD_FAILED);
         if (e->has_payload) {
-            if (!host_perm) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_upload: payload engine needs a permutation buffer");
             RSX_TRY(hipMemcpyAsync(e->perm[e->cur], host_perm, static_cast<size_t>(n) * 4, hipMemcpyHostToDevice, e->stream),
                     RSX_DATA_UPLOAD_FAILED);
         }
@@ -1544,6 +1544,7 @@ int rsx_partition(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, 
         return fail(RSX_HOST_BUFFERS_FAILED, "rsx_partition: key buffers must be 16-byte aligned device pointers");
     const bool with_payload = e->has_payload && d_payload && d_payload_out;
     if (e->has_payload && !with_payload && n > 0) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_partition: payload engine needs payload buffers");
+    if (with_payload && !aligned16(d_payload)) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_partition: the payload input must be 16-byte aligned (it is read 16 bytes per lane)");
     if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
     if (n == 0) {
         for (uint32_t d = 0; d <= buckets; ++d) bucket_offsets[d] = 0;
@@ -1604,6 +1605,7 @@ int rsx_partition_scatter(rsx_engine* e, const void* d_keys, const uint32_t* d_p
     if (!d_keys_out || !aligned16(d_keys_out)) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_partition_scatter: output must be a 16-byte aligned device pointer");
     const bool with_payload = e->has_payload && d_payload && d_payload_out;
     if (e->has_payload && !with_payload) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_partition_scatter: payload engine needs payload buffers");
+    if (with_payload && !aligned16(d_payload)) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_partition_scatter: the payload input must be 16-byte aligned (it is read 16 bytes per lane)");
     if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
     int rc = launch_scan(e, n);
     if (rc == RSX_OK) rc = launch_paste(e, n);
@@ -1682,6 +1684,7 @@ int rsx_partition_scatter_split(rsx_engine* e, const void* d_keys, const uint32_
     if (!d_keys_out || !aligned16(d_keys_out)) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_partition_scatter_split: output must be a 16-byte aligned device pointer");
     const bool with_payload = e->has_payload && d_payload && d_payload_out;
     if (e->has_payload && !with_payload) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_partition_scatter_split: payload engine needs payload buffers");
+    if (with_payload && !aligned16(d_payload)) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_partition_scatter_split: the payload input must be 16-byte aligned (it is read 16 bytes per lane)");
     if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
     int rc = launch_scan(e, n);
     if (rc == RSX_OK) rc = launch_paste(e, n);
@@ -1748,6 +1751,7 @@ int rsx_partition_scatter_waves(rsx_engine* e, const void* d_keys, const uint32_
     if (!d_keys_out || !aligned16(d_keys_out)) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_partition_scatter_waves: output must be a 16-byte aligned device pointer");
     const bool with_payload = e->has_payload && d_payload && d_payload_out;
     if (e->has_payload && !with_payload) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_partition_scatter_waves: payload engine needs payload buffers");
+    if (with_payload && !aligned16(d_payload)) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_partition_scatter_waves: the payload input must be 16-byte aligned (it is read 16 bytes per lane)");
     if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
     int rc = launch_scan(e, n);
     if (rc == RSX_OK) rc = launch_paste(e, n);
@@ -1788,6 +1792,7 @@ int rsx_partition_range(rsx_engine* e, const void* d_keys, const uint32_t* d_pay
         return fail(RSX_HOST_BUFFERS_FAILED, "rsx_partition_range: key buffers must be 16-byte aligned device pointers");
     const bool with_payload = e->has_payload && d_payload && d_payload_out;
     if (e->has_payload && !with_payload && n > 0) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_partition_range: payload engine needs payload buffers");
+    if (with_payload && !aligned16(d_payload)) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_partition_range: the payload input must be 16-byte aligned (it is read 16 bytes per lane)");
     if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
     if (n == 0) {
         for (uint32_t d = 0; d <= RSX_RADIX; ++d) bucket_offsets[d] = 0;

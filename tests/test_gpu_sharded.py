@@ -364,6 +364,35 @@ def test_partition_count_then_scatter(rsx, oracle):
             e.partition_scatter(tk.data_ptr(), n, 28, 4, out.data_ptr())
 
 
+def test_partition_refuses_a_misaligned_payload_input(rsx, oracle):
+    """The partition kernels read keys AND payload 16 bytes per lane: an input payload pointer that is not 16-byte
+    aligned is refused by every partition entry point instead of faulting on the device."""
+    import torch
+    n = 70000
+    keys = oracle.dataset("SeededUniform", "uint32", n)
+    tk = torch.from_numpy(keys.view(np.int32)).cuda()
+    pay = torch.arange(n + 4, dtype=torch.int32, device="cuda")
+    out, pout = torch.empty_like(tk), torch.empty(n, dtype=torch.int32, device="cuda")
+    bad = pay[1:].data_ptr()                                  # 4 bytes past a 16-byte boundary
+    with rsx.Engine("uint32", n, payload=True) as e:
+        e.set_stream(torch.cuda.current_stream().cuda_stream)
+        with pytest.raises(rsx.RadixSortError):
+            e.partition(tk.data_ptr(), n, 28, 4, out.data_ptr(), bad, pout.data_ptr())
+        e.partition_count(tk.data_ptr(), n, 28, 4)
+        with pytest.raises(rsx.RadixSortError):
+            e.partition_scatter(tk.data_ptr(), n, 28, 4, out.data_ptr(), bad, pout.data_ptr())
+        e.partition_count_waves(tk.data_ptr(), n, 4)
+        with pytest.raises(rsx.RadixSortError):
+            e.partition_scatter_waves(tk.data_ptr(), n, out.data_ptr(), bad, pout.data_ptr())
+        # and the aligned call still works afterwards
+        offs = e.partition(tk.data_ptr(), n, 28, 4, out.data_ptr(), pay.data_ptr(), pout.data_ptr())
+        torch.cuda.synchronize()
+        d = (keys >> np.uint32(28)).astype(np.int64)
+        order = np.argsort(d, kind="stable")
+        assert offs[-1] == n and np.array_equal(out.cpu().numpy().view(np.uint32), keys[order])
+        assert np.array_equal(pout.cpu().numpy(), order.astype(np.int32))
+
+
 # --------------------------------------------------------------------------- real processes, one rank each, sharing the one GPU
 @pytest.mark.parametrize("ranks,extra,env", [
     (2, ["--total-log2-keys", "23"], {}),
