@@ -607,6 +607,7 @@ int sort_selfscan_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* e
     return RSX_OK;
 }
 
+#if RSX_TILE_THREADS == 256      // (the 8-bit kernels are written for 256-thread tiles: one thread per digit)
 // 8-bit digits: per pass histogram8 -> scan8 (two launches) -> reorder8, half as many passes.  Taken by the sort
 // chain when RSX_OPT_RADIX_BITS is 8 and the pass range [first_pass, last_pass) — counted in 4-bit passes, as
 // everywhere in this API — covers whole bytes.
@@ -693,11 +694,14 @@ int sort8_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext
     return RSX_OK;
 }
 
+#endif
+
 template <typename Key>
 int sort_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext_perm, uint64_t count)
 {
     // (8-bit digits pay off from 2^19 keys: below that the 4-bit self-scan chain — 9 launches of a 1024- or 4096-key tile's
     // latency — is faster than 4 passes of four launches; same result either way)
+#if RSX_TILE_THREADS == 256
     if (e->radix_bits == 8 && count > e->radix8_min_keys && e->first_pass < e->last_pass && (e->first_pass & 1) == 0 && (e->last_pass & 1) == 0) {
         return sort8_chain_enqueue<Key>(e, ext_keys, ext_perm, count);
     }
@@ -720,6 +724,7 @@ int sort_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext_
         e->first_pass = first;
         return rc;
     }
+#endif
     if (e->tile_sort && e->profile != 1 && count > 0 && count <= static_cast<uint64_t>(kTileKeys) && e->first_pass < e->last_pass) {
         return sort_tile_enqueue<Key>(e, ext_keys, ext_perm, count);
     }
