@@ -258,6 +258,10 @@ int rsx_partition_scatter_split(rsx_engine* e, const void* d_keys, const uint32_
  * rsx_sort_from_to: rsx_sort_from over passes [first_pass, last_pass) whose last pass writes to the
  * caller's d_keys_out / d_payload_out (any alignment), e.g. at an offset inside the final array. */
 int rsx_partition_count_waves(rsx_engine* e, const void* d_keys, uint64_t n, int world, uint64_t* bucket_counts);
+/* The same count with the 16 sizes left in DEVICE memory (d_bucket_counts, 16 x uint64) and no host synchronisation: the caller
+ * hands that buffer straight to the collective that exchanges the counts (one host round trip per step instead of three).
+ * rsx_partition_scatter_waves follows as after rsx_partition_count_waves. */
+int rsx_partition_count_waves_device(rsx_engine* e, const void* d_keys, uint64_t n, int world, uint64_t* d_bucket_counts);
 int rsx_partition_scatter_waves(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n, void* d_keys_out, uint32_t* d_payload_out);
 int rsx_sort_from_to(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n, int first_pass, int last_pass, void* d_keys_out,
                      uint32_t* d_payload_out);

@@ -38,7 +38,7 @@ SYMBOLS = [
     "rsx_create", "rsx_destroy", "rsx_set_stream", "rsx_get_stream", "rsx_set_option", "rsx_get_geometry", "rsx_resize",
     "rsx_upload", "rsx_fill_pad", "rsx_download", "rsx_pin_host", "rsx_unpin_host", "rsx_pipeline_submit", "rsx_pipeline_wait", "rsx_host_device_pointer",
     "rsx_histogram", "rsx_scan", "rsx_paste", "rsx_reorder", "rsx_sort", "rsx_sync",
-    "rsx_sort_from", "rsx_partition", "rsx_partition_count", "rsx_partition_scatter", "rsx_sample_keys", "rsx_partition_count_split", "rsx_partition_scatter_split", "rsx_partition_count_waves", "rsx_partition_scatter_waves", "rsx_sort_from_to", "rsx_key_range", "rsx_partition_range", "rsx_result_device", "rsx_copy_result", "rsx_tile_map", "rsx_timings",
+    "rsx_sort_from", "rsx_partition", "rsx_partition_count", "rsx_partition_scatter", "rsx_sample_keys", "rsx_partition_count_split", "rsx_partition_scatter_split", "rsx_partition_count_waves", "rsx_partition_count_waves_device", "rsx_partition_scatter_waves", "rsx_sort_from_to", "rsx_key_range", "rsx_partition_range", "rsx_result_device", "rsx_copy_result", "rsx_tile_map", "rsx_timings",
 ]
 
 
@@ -136,6 +136,7 @@ def load_library() -> C.CDLL:
         "rsx_partition_count_split": ([P, P, U64, C.POINTER(U64), I, C.POINTER(U64)], I),
         "rsx_partition_scatter_split": ([P, P, P, U64, P, P], I),
         "rsx_partition_count_waves": ([P, P, U64, I, C.POINTER(U64)], I),
+        "rsx_partition_count_waves_device": ([P, P, U64, I, P], I),
         "rsx_partition_scatter_waves": ([P, P, P, U64, P, P], I),
         "rsx_sort_from_to": ([P, P, P, U64, I, I, P, P], I),
         "rsx_key_range": ([P, P, U64, C.POINTER(U64), C.POINTER(U64)], I),
@@ -341,6 +342,10 @@ class Engine:
         counts = (C.c_uint64 * 16)()
         self._check(self.lib.rsx_partition_count_waves(self._h, C.c_void_p(d_keys), n, world, counts), "rsx_partition_count_waves")
         return [int(v) for v in counts]
+
+    def partition_count_waves_device(self, d_keys: int, n: int, world: int, d_counts: int) -> None:
+        """The 16 wave-major bucket sizes into device memory (16 x uint64 at d_counts), asynchronously: no host round trip."""
+        self._check(self.lib.rsx_partition_count_waves_device(self._h, C.c_void_p(d_keys), n, world, C.c_void_p(d_counts)), "rsx_partition_count_waves_device")
 
     def partition_scatter_waves(self, d_keys: int, n: int, d_keys_out: int, d_payload: int | None = None, d_payload_out: int | None = None) -> None:
         self._check(self.lib.rsx_partition_scatter_waves(

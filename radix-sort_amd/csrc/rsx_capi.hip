@@ -1715,15 +1715,11 @@ int wave_rot_of(int world)
 }
 }  // namespace
 
-int rsx_partition_count_waves(rsx_engine* e, const void* d_keys, uint64_t n, int world, uint64_t* bucket_counts)
+namespace {
+// histogram of the wave-major buckets + the 16 totals in e->range_dev; nothing leaves the device, nothing synchronises
+int count_waves_enqueue(rsx_engine* e, const void* d_keys, uint64_t n, int rot, const char* who)
 {
-    if (!e || !bucket_counts) return fail(RSX_CALCULATION_FAILED, "rsx_partition_count_waves: null argument");
-    const int rot = wave_rot_of(world);
-    if (rot < 0) return fail(RSX_CALCULATION_FAILED, "rsx_partition_count_waves: world must be 1, 2, 4, 8 or 16");
-    if (n > e->capacity) return fail(RSX_RESIZE_FAILED, "rsx_partition_count_waves: beyond capacity");
-    for (int d = 0; d < RSX_RADIX; ++d) bucket_counts[d] = 0;
-    if (n == 0) return RSX_OK;
-    if (!d_keys || !aligned16(d_keys)) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_partition_count_waves: keys must be a 16-byte aligned device pointer");
+    if (!d_keys || !aligned16(d_keys)) return fail(RSX_HOST_BUFFERS_FAILED, who);
     if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
     const int shift = e->key_bytes * 8 - RSX_RADIX_BITS;
     e->wave_rot = static_cast<uint32_t>(rot % RSX_RADIX_BITS);        // world 1: 16 waves of one bucket, identity order
@@ -1733,12 +1729,47 @@ int rsx_partition_count_waves(rsx_engine* e, const void* d_keys, uint64_t n, int
     if (rc != RSX_OK) return rc;
     hipLaunchKernelGGL(rsx::digit_totals_kernel, dim3(RSX_RADIX), dim3(256), 0, e->stream, e->table, static_cast<uint32_t>(e->ntiles(n)), e->range_dev);
     RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
+    return RSX_OK;
+}
+}  // namespace
+
+int rsx_partition_count_waves(rsx_engine* e, const void* d_keys, uint64_t n, int world, uint64_t* bucket_counts)
+{
+    if (!e || !bucket_counts) return fail(RSX_CALCULATION_FAILED, "rsx_partition_count_waves: null argument");
+    const int rot = wave_rot_of(world);
+    if (rot < 0) return fail(RSX_CALCULATION_FAILED, "rsx_partition_count_waves: world must be 1, 2, 4, 8 or 16");
+    if (n > e->capacity) return fail(RSX_RESIZE_FAILED, "rsx_partition_count_waves: beyond capacity");
+    for (int d = 0; d < RSX_RADIX; ++d) bucket_counts[d] = 0;
+    if (n == 0) return RSX_OK;
+    const int rc = count_waves_enqueue(e, d_keys, n, rot, "rsx_partition_count_waves: keys must be a 16-byte aligned device pointer");
+    if (rc != RSX_OK) return rc;
     RSX_TRY(hipMemcpyAsync(e->range_host, e->range_dev, RSX_RADIX * 8, hipMemcpyDeviceToHost, e->stream), RSX_CALCULATION_FAILED);
     RSX_TRY(hipStreamSynchronize(e->stream), RSX_CALCULATION_FAILED);
     for (int d = 0; d < RSX_RADIX; ++d) bucket_counts[d] = e->range_host[d];
     e->counted_keys = d_keys;
     e->counted_n = n;
     e->counted_shift = -2;            // marks a wave-major count
+    e->counted_bits = rot;
+    return RSX_OK;
+}
+
+int rsx_partition_count_waves_device(rsx_engine* e, const void* d_keys, uint64_t n, int world, uint64_t* d_bucket_counts)
+{
+    if (!e || !d_bucket_counts) return fail(RSX_CALCULATION_FAILED, "rsx_partition_count_waves_device: null argument");
+    const int rot = wave_rot_of(world);
+    if (rot < 0) return fail(RSX_CALCULATION_FAILED, "rsx_partition_count_waves_device: world must be 1, 2, 4, 8 or 16");
+    if (n > e->capacity) return fail(RSX_RESIZE_FAILED, "rsx_partition_count_waves_device: beyond capacity");
+    if (n == 0) {
+        if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
+        RSX_TRY(hipMemsetAsync(d_bucket_counts, 0, RSX_RADIX * 8, e->stream), RSX_CALCULATION_FAILED);
+        return RSX_OK;
+    }
+    const int rc = count_waves_enqueue(e, d_keys, n, rot, "rsx_partition_count_waves_device: keys must be a 16-byte aligned device pointer");
+    if (rc != RSX_OK) return rc;
+    RSX_TRY(hipMemcpyAsync(d_bucket_counts, e->range_dev, RSX_RADIX * 8, hipMemcpyDeviceToDevice, e->stream), RSX_CALCULATION_FAILED);
+    e->counted_keys = d_keys;
+    e->counted_n = n;
+    e->counted_shift = -2;
     e->counted_bits = rot;
     return RSX_OK;
 }

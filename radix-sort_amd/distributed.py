@@ -314,6 +314,7 @@ class ShardedSorter:
         # events on the current stream, which must be the engine's stream); read with timeline_ms()
         self.record_timeline = False
         self._marks = []
+        self._count_row = self._count_table = self._count_row_caps = None      # device row of the pipelined path's counts (+ capacities)
 
     def _mark(self, label):
         if self.record_timeline:
@@ -411,8 +412,13 @@ class ShardedSorter:
         """Pipelined fast path; returns None (nothing moved yet) when the fixed bucket ownership
         would leave a rank with more than max_imbalance x its share."""
         world, k = self.world, RADIX // self.world
-        counts = self.engine.partition_count_waves(keys.data_ptr(), n, world)          # [wave * world + rank]
-        table, caps = gather_counts(counts, world, self.dist, keys.device, self._caps)   # [source][wave * world + rank]
+        if self.dist is not None and getattr(keys, "is_cuda", False) and hasattr(self.engine, "partition_count_waves_device"):
+            # the counts never visit the host on their way into the all_gather: one host round trip (the gathered table) per step
+            table, caps = self._gather_wave_counts_on_device(keys, n)
+            counts = table[self.rank]
+        else:
+            counts = self.engine.partition_count_waves(keys.data_ptr(), n, world)          # [wave * world + rank]
+            table, caps = gather_counts(counts, world, self.dist, keys.device, self._caps)   # [source][wave * world + rank]
         loads = [sum(row[w * world + d] for row in table for w in range(k)) for d in range(world)]
         total = sum(loads)
         imbalance = max(loads) / max(1.0, total / world)
@@ -462,6 +468,23 @@ class ShardedSorter:
             done += n_recv
         self.last_path, self.last_imbalance, self.result_in_out = "waves", imbalance, True
         return done
+
+    def _gather_wave_counts_on_device(self, keys, n):
+        """gather_counts for the pipelined path without the host in the middle: the engine leaves its 16 counts in a device
+        row that also carries this rank's two buffer capacities, the row goes into the all_gather as it is, and only the
+        gathered table is copied to the host."""
+        import torch
+        if self._count_row is None or self._count_row.device != keys.device:
+            self._count_row = torch.zeros(RADIX + 2, dtype=torch.int64, device=keys.device)
+            self._count_table = torch.empty(self.world * (RADIX + 2), dtype=torch.int64, device=keys.device)
+            self._count_row_caps = None
+        if self._count_row_caps != self._caps:
+            self._count_row[RADIX:] = torch.tensor([int(self._caps[0]), int(self._caps[1])], dtype=torch.int64)
+            self._count_row_caps = self._caps
+        self.engine.partition_count_waves_device(keys.data_ptr(), n, self.world, self._count_row.data_ptr())
+        self.dist.all_gather_into_tensor(self._count_table, self._count_row)
+        rows = self._count_table.cpu().view(self.world, RADIX + 2).tolist()
+        return [r[:RADIX] for r in rows], [(r[RADIX], r[RADIX + 1]) for r in rows]
 
     def _sort_by_splitters(self, keys, n, staging, recv, payload, staging_payload, recv_payload, pay_in, pay_st):
         count = min(SAMPLES_PER_RANK, n)

@@ -364,6 +364,35 @@ def test_partition_count_then_scatter(rsx, oracle):
             e.partition_scatter(tk.data_ptr(), n, 28, 4, out.data_ptr())
 
 
+@pytest.mark.parametrize("dt,world", [("uint32", 8), ("int64", 2), ("uint64", 16)])
+def test_wave_counts_left_on_the_device(rsx, oracle, dt, world):
+    """rsx_partition_count_waves_device leaves the same 16 sizes in device memory (no host round trip) and arms the same
+    scatter; n = 0 zeroes the row."""
+    import torch
+    n = 300001
+    keys = oracle.dataset("SeededUniform", dt, n, seed=world)
+    signed = {"uint32": np.int32, "uint64": np.int64}.get(dt)
+    tk = torch.from_numpy(keys.view(signed) if signed else keys).cuda()
+    out = torch.empty_like(tk)
+    row = torch.full((18,), -1, dtype=torch.int64, device="cuda")
+    with rsx.Engine(dt, n) as e:
+        e.set_stream(torch.cuda.current_stream().cuda_stream)
+        want = e.partition_count_waves(tk.data_ptr(), n, world)
+        e.partition_scatter_waves(tk.data_ptr(), n, out.data_ptr())
+        torch.cuda.synchronize()
+        first = out.cpu().numpy().copy()
+        e.partition_count_waves_device(tk.data_ptr(), n, world, row.data_ptr())
+        e.partition_scatter_waves(tk.data_ptr(), n, out.data_ptr())
+        torch.cuda.synchronize()
+        assert row[:16].cpu().tolist() == want and row[16:].cpu().tolist() == [-1, -1]
+        assert np.array_equal(out.cpu().numpy(), first)
+        e.partition_count_waves_device(tk.data_ptr(), 0, world, row.data_ptr())
+        torch.cuda.synchronize()
+        assert row[:16].cpu().tolist() == [0] * 16
+        with pytest.raises(rsx.RadixSortError):
+            e.partition_count_waves_device(tk.data_ptr(), n, 3, row.data_ptr())
+
+
 def test_partition_refuses_a_misaligned_payload_input(rsx, oracle):
     """The partition kernels read keys AND payload 16 bytes per lane: an input payload pointer that is not 16-byte
     aligned is refused by every partition entry point instead of faulting on the device."""
