@@ -67,6 +67,20 @@ def make_input(kind: str, dtype: str, n: int, seed: int) -> np.ndarray:
     return out
 
 
+def make_shard(kind: str, dtype: str, offset: int, n: int, total: int, seed: int) -> np.ndarray:
+    """Elements [offset, offset + n) of the `total`-element dataset (host C ABI rsxh_dataset_fill_shard): a rank's contiguous
+    shard of ONE dataset — BASELINE config 4 is `Random` (Dataset.h:110-120) sharded contiguously, so rank r takes the
+    generator's stream from draw r*n on (std::mt19937::discard)."""
+    lib = C.CDLL(os.path.join(ROOT, "radix-sort_amd", "host", "libradixsort_host.so"))
+    lib.rsxh_dataset_fill_shard.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]
+    lib.rsxh_dataset_fill_shard.restype = C.c_int
+    out = np.empty(n, dtype=dtype)
+    rc = lib.rsxh_dataset_fill_shard(KIND_CODES[kind], DTYPE_CODES[dtype], out.ctypes.data, offset, n, total, seed)
+    if rc != 0:
+        raise RuntimeError(f"rsxh_dataset_fill_shard failed: {rc}")
+    return out
+
+
 def torch_view(t_np: np.ndarray):
     import torch
     signed = {"uint32": np.int32, "uint64": np.int64}.get(t_np.dtype.name)
@@ -215,10 +229,17 @@ def main() -> None:
         scaling = "weak"
     key_bytes = np.dtype(args.dtype).itemsize
     pay_bytes = 4 if args.payload else 0
-    # N=1: the reference's Random generator.  N>1: independent per-rank streams of the
-    # seeded uniform generator (Random's fixed seed would give every rank the same shard).
-    kind = args.dataset if not sharded else ("RandomDistributed" if args.dataset == "Random" else args.dataset)
-    host_keys = make_input(kind, args.dtype, n, BASE_SEED + rank)
+    # N=1: the reference's Random generator.  N>1 with a fixed TOTAL (strong scaling, BASELINE config 4): every rank holds its
+    # contiguous n-key shard of the ONE dataset of n*world keys — for Random, draws rank*n .. rank*n+n-1 of the generator's
+    # stream.  N>1 with a fixed size PER GPU (weak scaling): independent per-rank streams of the seeded uniform generator
+    # (there is no "one dataset" whose size grows with the rank count in the reference).
+    one_dataset = sharded and scaling == "strong"
+    if one_dataset:
+        kind = args.dataset
+        host_keys = make_shard(kind, args.dtype, rank * n, n, n * world, BASE_SEED)
+    else:
+        kind = args.dataset if not sharded else ("RandomDistributed" if args.dataset == "Random" else args.dataset)
+        host_keys = make_input(kind, args.dtype, n, BASE_SEED + rank)
     keys = torch_view(host_keys).to(device)
     payload = torch.arange(n, dtype=torch.int32, device=device) if args.payload else None
 
@@ -238,6 +259,9 @@ def main() -> None:
     if args.radix_bits != 4:
         eng.set_option(rsx.OPT_RADIX_BITS, args.radix_bits)
     sorter = ShardedSorter(eng, rank, world, key_bytes * 8, dist, force_exchange=force_exchange, strategy=os.environ.get("RSX_STRATEGY", "auto"))
+    if sharded and sorter.strategy == "waves-p2p":
+        # peer-store exchange: the receive buffers are peer-visible device memory that the other ranks' scatter kernels write into
+        sorter.setup_peer_exchange(capacity, device, args.payload)
     staging = recv = spay = rpay = obuf = opay = None
     if sharded:
         staging = torch.empty_like(keys)
@@ -272,6 +296,8 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     rt = eng.timings(reset=True)
+    if hasattr(eng, "sync"):
+        eng.sync()              # also reports a fused table scan that timed out in the last step (earlier ones: the sorter's check)
     eng.set_option(rsx.OPT_PROFILE, 1)
     sorter.record_timeline = sharded and not rehearsal
     for _ in range(2):
@@ -344,7 +370,11 @@ def main() -> None:
                     sizes = [r[0] for r in rows]
                     cat = np.concatenate([p[:sz].cpu().numpy() for p, sz in zip(parts, sizes)]).view(np.dtype(args.dtype))
                     del parts
-                    everything = np.concatenate([host_keys] + [make_input(kind, args.dtype, n, BASE_SEED + r) for r in range(1, world)])
+                    if one_dataset:
+                        everything = make_shard(kind, args.dtype, 0, n * world, n * world, BASE_SEED)
+                        assert np.array_equal(everything[:n], host_keys)
+                    else:
+                        everything = np.concatenate([host_keys] + [make_input(kind, args.dtype, n, BASE_SEED + r) for r in range(1, world)])
                     everything.sort()          # keys only: any correct sort gives the same array (numpy's default is the fast one: ~10 s for 2^30 uint32)
                     flag[0] = int(np.array_equal(cat, everything))
                     del cat, everything
@@ -363,7 +393,7 @@ def main() -> None:
     # wave by wave on the pipelined path), so the figure is bytes of all launches / time of all launches
     passes = key_bytes * 8 // args.radix_bits
     if sharded:
-        local_passes = passes - 1 if sorter.last_path == "waves" else passes
+        local_passes = passes - 1 if sorter.last_path in ("waves", "waves-p2p") else passes
         scatter_bytes_per_step = 2.0 * (key_bytes + pay_bytes) * (n + local_passes * n_local)
         scatter_bytes = scatter_bytes_per_step / launches_per_step if launches_per_step else 0.0
     else:
@@ -374,9 +404,10 @@ def main() -> None:
         return f"2^{v.bit_length() - 1}" if v & (v - 1) == 0 else str(v)
     workload = f"{pow2(n)} {args.dtype}{'+u32 payload' if args.payload else ''} {kind}, {args.radix_bits}-bit digits, {passes} passes"
     if world > 1:
-        workload = f"{pow2(total_keys)} {args.dtype}{'+u32 payload' if args.payload else ''} keys sharded {world}x ({pow2(n)} per GPU, {kind}), RCCL histogram all-gather + key all-to-all over xGMI, {args.radix_bits}-bit digits"
-        if total_keys == 1 << 30 and args.dtype == "uint32" and not args.payload and args.radix_bits == 4:
-            workload += " [BASELINE config 4]"
+        shards = f"contiguous shards of one {kind} dataset" if one_dataset else f"{kind} per rank"
+        workload = f"{pow2(total_keys)} {args.dtype}{'+u32 payload' if args.payload else ''} keys sharded {world}x ({pow2(n)} per GPU, {shards}), RCCL histogram all-gather + key all-to-all over xGMI, {args.radix_bits}-bit digits"
+        if total_keys == 1 << 30 and args.dtype == "uint32" and not args.payload and args.radix_bits == 4 and one_dataset and kind == "Random":
+            workload += " [BASELINE config 4]" if world == 8 else f" [BASELINE config 4's input and size over {world} ranks]"
     line = {
         "metric": METRIC,
         "value": round(total_keys / (elapsed / args.steps) * 1e-6, 1),
@@ -387,7 +418,9 @@ def main() -> None:
         "dtype": {"uint32": "u32", "int32": "i32", "uint64": "u64", "int64": "i64"}[args.dtype],
         "data": "synthetic",
         "config": {"workload": workload, "keys_per_gpu": n, "total_keys": total_keys,
-                   "parallelism": "single GPU" if not sharded else f"msd-partition[{sorter.last_path}] x{world} + all_to_all (RCCL) + local LSD sort",
+                   "parallelism": "single GPU" if not sharded else (
+                       f"msd-partition[{sorter.last_path}] x{world} + peer stores into the owners' receive buffers + local LSD sort" if sorter.last_path == "waves-p2p"
+                       else f"msd-partition[{sorter.last_path}] x{world} + all_to_all (RCCL) + local LSD sort"),
                    "verified": verified},
         "roofline": {
             "bound": "hbm", "kernel": "reorder_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -415,6 +448,10 @@ def main() -> None:
         line["rehearsal"] = True
     if rank == 0:
         print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()          # nobody unmaps or frees a receive buffer a peer may still be writing into
+    if getattr(sorter, "_peer", None) is not None:
+        sorter.close_peer_exchange()
     eng.close()
     if dist is not None:
         dist.barrier()

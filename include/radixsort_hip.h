@@ -73,6 +73,14 @@ typedef enum rsx_option {
     RSX_OPT_FUSED_SCAN = 9,   /* 1 (default): inside rsx_sort, tables of up to 512 scan groups (2^29 keys) are scanned and pasted in
                                  ONE launch whose workgroups hand their group sums to each other through tagged 8-byte
                                  granules; 0: scan #1, then scan #2 + paste (two launches).  Same table either way. */
+    RSX_OPT_FUSED_SCAN_MAX_GROUPS = 15, /* largest table, in scan groups of 256 tiles (2^20 keys each), that takes the fused scan.  Its workgroups
+                                 wait for each other inside the launch, so the whole grid must be resident at once: rsx_create asks
+                                 hipOccupancyMaxActiveBlocksPerMultiprocessor x the CU count how many workgroups the device holds and takes
+                                 HALF of it as the default (at most 512), which leaves room for a second engine scanning on another
+                                 stream of the same device; engines that scan at the same time share that budget — a caller running k > 2
+                                 of them concurrently on one device sets resident / k here.  Values are clamped to what is resident; -1 =
+                                 default; 0 = never.  Larger tables take scan #1, then scan #2 + paste (two launches), same table. */
+    RSX_OPT_DEBUG_RAISE_SCAN_TIMEOUT = 16, /* tests only: enqueue the store a timed-out fused scan makes (see rsx_check_status) */
     RSX_OPT_RADIX_BITS = 10,  /* digit width of the rsx_sort chain: 4 (default, the reference's _NUM_BITS_PER_RADIX, src/Parameters.h:25) or 8.
                                  With 8 a pass sorts by a whole byte (two stable 4-bit rounds inside LDS, one scatter of up to
                                  256 runs per tile): half the passes over HBM.  Same result.  Pass ranges (RSX_OPT_FIRST_PASS /
@@ -122,6 +130,8 @@ typedef struct rsx_geometry {
     uint64_t num_scan_blocks;  /* 16 * ceil(num_tiles / scan_block) = live entries of globsum, layout [digit][group] */
     uint32_t num_passes;       /* key bits / 4 */
     uint32_t key_bytes;
+    uint32_t fused_scan_resident;   /* workgroups of the fused table scan the device holds at once (occupancy query x CU count) */
+    uint32_t fused_scan_max_groups; /* largest table, in scan groups, that takes the fused scan (RSX_OPT_FUSED_SCAN_MAX_GROUPS) */
 } rsx_geometry;
 
 /* ---- device --------------------------------------------------------------- */
@@ -202,6 +212,14 @@ int rsx_paste(rsx_engine* e);
 int rsx_reorder(rsx_engine* e, int pass);
 int rsx_sort(rsx_engine* e);
 int rsx_sync(rsx_engine* e);   /* CommandQueue.finish() */
+/* The fused table scan bounds its polls; a workgroup whose poll ran out (its grid was not resident at once — a device
+ * shared with long-running kernels of other processes, see RSX_OPT_FUSED_SCAN_MAX_GROUPS) stores to a word of mapped host
+ * memory and finishes, leaving that sort's result undefined.  The word is reported ONCE — by rsx_sync, rsx_download,
+ * rsx_pipeline_wait (after their synchronisation), and by rsx_check_status / rsx_copy_result without synchronising, i.e. for
+ * sorts that have already finished — with RSX_CALCULATION_FAILED / RSX_DATA_DOWNLOAD_FAILED, and is then cleared: the
+ * engine stays usable.  Asynchronous callers (rsx_sort_from_to into their own buffers) end a batch with rsx_sync, or
+ * call rsx_check_status after synchronising the stream themselves. */
+int rsx_check_status(rsx_engine* e);
 
 /* ---- device-resident callers (PyTorch / RCCL plumbing) ----------------------
  * rsx_sort_from: sorts n keys that already live in HBM at d_keys (16-byte
@@ -265,6 +283,23 @@ int rsx_partition_count_waves_device(rsx_engine* e, const void* d_keys, uint64_t
 int rsx_partition_scatter_waves(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n, void* d_keys_out, uint32_t* d_payload_out);
 int rsx_sort_from_to(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n, int first_pass, int last_pass, void* d_keys_out,
                      uint32_t* d_payload_out);
+/* Peer-store exchange (a selectable alternative to the all-to-all of the pipelined path): the wave-major scatter writes every bucket
+ * STRAIGHT into the receive buffer of the rank that owns it — no staging write, no re-read, no collective on the data path.
+ * rsx_partition_scatter_waves_peer follows rsx_partition_count_waves[_device] like rsx_partition_scatter_waves; peer_keys[p] (p = 0..15,
+ * wave-major position = wave * world + destination rank) is the address where THIS rank's keys of bucket p begin in the destination's
+ * buffer (the caller derives it from the gathered count table: destination base + keys of earlier waves + keys of lower-ranked sources
+ * in that wave); peer_payload likewise for payload engines.  Addresses need the alignment of one element only.  Asynchronous; the
+ * destinations may read their buffers once every source's scatter has finished (the caller's cross-rank barrier on the stream).
+ * Receive buffers other ranks can write to: rsx_peer_alloc (hipMalloc + an IPC handle to hand to the other PROCESSES, which map it
+ * with rsx_peer_open / rsx_peer_close — lazy peer access over xGMI); ranks that are threads of one process use the pointer itself
+ * (rsx_peer_enable once per other device). */
+#define RSX_IPC_HANDLE_BYTES 64
+int rsx_partition_scatter_waves_peer(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n, void* const* peer_keys, uint32_t* const* peer_payload);
+int rsx_peer_alloc(rsx_engine* e, uint64_t bytes, void** d_ptr, void* ipc_handle /* RSX_IPC_HANDLE_BYTES bytes, or NULL */);
+int rsx_peer_free(rsx_engine* e, void* d_ptr);
+int rsx_peer_open(rsx_engine* e, const void* ipc_handle, void** d_ptr);
+int rsx_peer_close(rsx_engine* e, void* d_ptr);
+int rsx_peer_enable(rsx_engine* e, int peer_device);
 int rsx_key_range(rsx_engine* e, const void* d_keys, uint64_t n, uint64_t* lo, uint64_t* hi);
 int rsx_partition_range(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n, uint64_t lo, int shift, uint64_t mul,
                         void* d_keys_out, uint32_t* d_payload_out, uint64_t* bucket_offsets);

@@ -30,15 +30,15 @@ STATUS_NAMES = [
     "PROGRAM_CREATION_FAILED", "NO_SOURCE_FOUND", "LOADING_SOURCE_FAILED",
 ]
 
-OPT_PROFILE, OPT_XCD_REMAP, OPT_FIRST_PASS, OPT_LAST_PASS, OPT_LOOKAHEAD, OPT_REF_DIAGNOSTICS, OPT_GRAPH, OPT_SMALL_SCAN, OPT_TILE_SORT, OPT_FUSED_SCAN, OPT_RADIX_BITS, OPT_SELF_SCAN, OPT_SMALL_TILE_MAX_KEYS, OPT_XCD_PHASE, OPT_SELF_SCAN_MAX_TILES = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14
+OPT_PROFILE, OPT_XCD_REMAP, OPT_FIRST_PASS, OPT_LAST_PASS, OPT_LOOKAHEAD, OPT_REF_DIAGNOSTICS, OPT_GRAPH, OPT_SMALL_SCAN, OPT_TILE_SORT, OPT_FUSED_SCAN, OPT_RADIX_BITS, OPT_SELF_SCAN, OPT_SMALL_TILE_MAX_KEYS, OPT_XCD_PHASE, OPT_SELF_SCAN_MAX_TILES, OPT_FUSED_SCAN_MAX_GROUPS, OPT_DEBUG_RAISE_SCAN_TIMEOUT = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16
 
 # every symbol include/radixsort_hip.h declares (tests/test_capi_symbols.py checks the header against this)
 SYMBOLS = [
     "rsx_device_count", "rsx_device_name", "rsx_last_error", "rsx_version",
     "rsx_create", "rsx_destroy", "rsx_set_stream", "rsx_get_stream", "rsx_set_option", "rsx_get_geometry", "rsx_resize",
     "rsx_upload", "rsx_fill_pad", "rsx_download", "rsx_pin_host", "rsx_unpin_host", "rsx_pipeline_submit", "rsx_pipeline_wait", "rsx_host_device_pointer",
-    "rsx_histogram", "rsx_scan", "rsx_paste", "rsx_reorder", "rsx_sort", "rsx_sync",
-    "rsx_sort_from", "rsx_partition", "rsx_partition_count", "rsx_partition_scatter", "rsx_sample_keys", "rsx_partition_count_split", "rsx_partition_scatter_split", "rsx_partition_count_waves", "rsx_partition_count_waves_device", "rsx_partition_scatter_waves", "rsx_sort_from_to", "rsx_key_range", "rsx_partition_range", "rsx_result_device", "rsx_copy_result", "rsx_tile_map", "rsx_timings",
+    "rsx_histogram", "rsx_scan", "rsx_paste", "rsx_reorder", "rsx_sort", "rsx_sync", "rsx_check_status",
+    "rsx_sort_from", "rsx_partition", "rsx_partition_count", "rsx_partition_scatter", "rsx_sample_keys", "rsx_partition_count_split", "rsx_partition_scatter_split", "rsx_partition_count_waves", "rsx_partition_count_waves_device", "rsx_partition_scatter_waves", "rsx_partition_scatter_waves_peer", "rsx_peer_alloc", "rsx_peer_free", "rsx_peer_open", "rsx_peer_close", "rsx_peer_enable", "rsx_sort_from_to", "rsx_key_range", "rsx_partition_range", "rsx_result_device", "rsx_copy_result", "rsx_tile_map", "rsx_timings",
 ]
 
 
@@ -55,6 +55,7 @@ class Geometry(C.Structure):
         ("tile_threads", C.c_uint32), ("keys_per_thread", C.c_uint32), ("tile_keys", C.c_uint32), ("scan_block", C.c_uint32),
         ("num_keys", C.c_uint64), ("capacity", C.c_uint64), ("num_tiles", C.c_uint64), ("table_len", C.c_uint64),
         ("num_scan_blocks", C.c_uint64), ("num_passes", C.c_uint32), ("key_bytes", C.c_uint32),
+        ("fused_scan_resident", C.c_uint32), ("fused_scan_max_groups", C.c_uint32),
     ]
 
 
@@ -128,6 +129,7 @@ def load_library() -> C.CDLL:
         "rsx_reorder": ([P, I], I),
         "rsx_sort": ([P], I),
         "rsx_sync": ([P], I),
+        "rsx_check_status": ([P], I),
         "rsx_sort_from": ([P, P, P, U64], I),
         "rsx_partition": ([P, P, P, U64, I, I, P, P, C.POINTER(U64)], I),
         "rsx_partition_count": ([P, P, U64, I, I, C.POINTER(U64)], I),
@@ -138,6 +140,12 @@ def load_library() -> C.CDLL:
         "rsx_partition_count_waves": ([P, P, U64, I, C.POINTER(U64)], I),
         "rsx_partition_count_waves_device": ([P, P, U64, I, P], I),
         "rsx_partition_scatter_waves": ([P, P, P, U64, P, P], I),
+        "rsx_partition_scatter_waves_peer": ([P, P, P, U64, C.POINTER(P), C.POINTER(P)], I),
+        "rsx_peer_alloc": ([P, U64, C.POINTER(P), P], I),
+        "rsx_peer_free": ([P, P], I),
+        "rsx_peer_open": ([P, P, C.POINTER(P)], I),
+        "rsx_peer_close": ([P, P], I),
+        "rsx_peer_enable": ([P, I], I),
         "rsx_sort_from_to": ([P, P, P, U64, I, I, P, P], I),
         "rsx_key_range": ([P, P, U64, C.POINTER(U64), C.POINTER(U64)], I),
         "rsx_partition_range": ([P, P, P, U64, U64, I, U64, P, P, C.POINTER(U64)], I),
@@ -279,6 +287,10 @@ class Engine:
     def sync(self) -> None:
         self._check(self.lib.rsx_sync(self._h), "rsx_sync")
 
+    def check_status(self) -> None:
+        """Raises if a fused table scan of a sort that has already finished timed out (no synchronisation; reported once)."""
+        self._check(self.lib.rsx_check_status(self._h), "rsx_check_status")
+
     def download(self, want_perm: bool = False, hist_cap: int = 0, globsum_cap: int = 0):
         n = self.geometry().num_keys
         keys = np.empty(n, dtype=self.dtype)
@@ -351,6 +363,33 @@ class Engine:
         self._check(self.lib.rsx_partition_scatter_waves(
             self._h, C.c_void_p(d_keys), C.c_void_p(d_payload) if d_payload else None, n,
             C.c_void_p(d_keys_out), C.c_void_p(d_payload_out) if d_payload_out else None), "rsx_partition_scatter_waves")
+
+    def partition_scatter_waves_peer(self, d_keys: int, n: int, peer_keys: list[int], d_payload: int | None = None, peer_payload: list[int] | None = None) -> None:
+        """The wave-major scatter with every bucket written straight to its own destination address (16 of them)."""
+        pk = (C.c_void_p * 16)(*peer_keys)
+        pp = (C.c_void_p * 16)(*peer_payload) if peer_payload is not None else None
+        self._check(self.lib.rsx_partition_scatter_waves_peer(self._h, C.c_void_p(d_keys), C.c_void_p(d_payload) if d_payload else None, n, pk, pp),
+                    "rsx_partition_scatter_waves_peer")
+
+    def peer_alloc(self, nbytes: int) -> tuple[int, bytes]:
+        """A device buffer other ranks may write to: (address, IPC handle for other processes)."""
+        p, h = C.c_void_p(), C.create_string_buffer(64)
+        self._check(self.lib.rsx_peer_alloc(self._h, nbytes, C.byref(p), h), "rsx_peer_alloc")
+        return int(p.value), h.raw
+
+    def peer_free(self, d_ptr: int) -> None:
+        self._check(self.lib.rsx_peer_free(self._h, C.c_void_p(d_ptr)), "rsx_peer_free")
+
+    def peer_open(self, handle: bytes) -> int:
+        p = C.c_void_p()
+        self._check(self.lib.rsx_peer_open(self._h, C.create_string_buffer(handle, 64), C.byref(p)), "rsx_peer_open")
+        return int(p.value)
+
+    def peer_close(self, d_ptr: int) -> None:
+        self._check(self.lib.rsx_peer_close(self._h, C.c_void_p(d_ptr)), "rsx_peer_close")
+
+    def peer_enable(self, peer_device: int) -> None:
+        self._check(self.lib.rsx_peer_enable(self._h, peer_device), "rsx_peer_enable")
 
     def sort_from_to(self, d_keys: int, n: int, first_pass: int, last_pass: int, d_keys_out: int,
                      d_payload: int | None = None, d_payload_out: int | None = None) -> None:

@@ -121,8 +121,12 @@ struct rsx_engine {
     int paste_scan = 1;                         // rsx_sort: scan #2 + paste in one launch (env RSX_PASTE_SCAN)
     int fused_scan = 1;                         // rsx_sort: scan #1, scan #2 and paste in ONE launch, arrival counter inside (env RSX_FUSED_SCAN)
     unsigned long long* gsums = nullptr;        // fused scan: {epoch, raw group sum} granules [group][16]
-    uint32_t* scan_timeout = nullptr;           // fused scan: set by a workgroup whose poll ran out (device) ...
-    uint32_t* scan_timeout_host = nullptr;      // ... and its pinned mirror, checked in rsx_sync / rsx_download
+    uint32_t* scan_timeout = nullptr;           // fused scan: set by a workgroup whose poll ran out — the DEVICE address of ...
+    uint32_t* scan_timeout_host = nullptr;      // ... this word of mapped pinned host memory: the host reads it without a copy (check_scan_timeout)
+    uint32_t fused_scan_resident = 0;           // workgroups of scan_fused_kernel the device holds at once (occupancy query x CU count, rsx_create)
+    uint32_t fused_scan_limit = 0;              // largest table, in scan groups, that takes the fused scan (RSX_OPT_FUSED_SCAN_MAX_GROUPS; default: half of the above)
+    bool table_valid = false;                   // e->table holds the last pass's table in the engine's own [digit][4096-key tile] geometry ...
+    bool globsum_valid = false;                 // ... and globsum_live its group sums (rsx_download refuses to hand out anything else)
     uint32_t scan_epoch = 0;                    // launch count of the fused scan (tags the granules; never 0)
     uint32_t* temp = nullptr;                   // grand total of scan #2
     uint32_t* counts_next = nullptr;            // look-ahead histogram of the next pass, [tile][digit]
@@ -149,6 +153,7 @@ struct rsx_engine {
     uint32_t* starts_dev = nullptr;             // 16 bucket starts (rsx_partition)
     uint32_t* starts_host = nullptr;            // pinned mirror
     uint64_t table_cap = 0;
+    unsigned long long* peer_dev = nullptr;     // peer-store exchange: 16 key + 16 payload destination addresses (allocated on first use)
 
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -175,6 +180,7 @@ struct rsx_engine {
     int small_scan = 1;         // rsx_sort: one-workgroup scan+paste for tables of <= 1024 tiles (env RSX_SMALL_SCAN)
     uint64_t radix8_min_keys = 1u << 19;        // 8-bit passes only above this many keys (env RSX_RADIX8_MIN_KEYS; at least one tile)
     int radix_bits = 4;         // RSX_OPT_RADIX_BITS: 4 (the reference's configuration) or 8 (half the passes; rsx_sort chain only)
+    int reorder8_version = 2;   // env RSX_REORDER8_V: 2 = keys make one trip through LDS (round 3), 1 = the two-trip kernel of round 2 (kept for A/B)
     bool radix8_ready = false;                  // the five tables below exist and the reorder8 kernels may use their LDS
     uint32_t* counts8 = nullptr;                // 8-bit digits: raw counts [tile][256] (allocated on first use)
     uint32_t* table8 = nullptr;                 //   group-local exclusive prefixes [tile][256]
@@ -290,6 +296,8 @@ int launch_histogram(rsx_engine* e, const void* in, uint64_t count, int shift, u
 {
     if (count == 0) return RSX_OK;
     e->counted_keys = nullptr;          // e->table is about to be overwritten: an earlier rsx_partition_count* is void
+    e->table_valid = true;
+    e->globsum_valid = false;
     const Grid g = grid_for(e, count);
     Bracket b(e, PH_HISTO);
     hipLaunchKernelGGL((rsx::histogram_kernel<Key, kTileThreads, kKeysPerThread, RANGED>), dim3(g.blocks), dim3(kTileThreads), 0, e->stream,
@@ -307,6 +315,8 @@ int launch_scan(rsx_engine* e, uint64_t count, bool from_counts = false, bool sc
     const uint32_t ntiles = static_cast<uint32_t>(e->ntiles(count));
     const uint32_t ngroups = (ntiles + rsx::kScanTiles - 1) / rsx::kScanTiles;
     e->globsum_live = e->globsum;
+    e->table_valid = true;
+    e->globsum_valid = true;
     {
         Bracket b(e, PH_SCAN);
         if (from_counts && e->scan_zeroes) {
@@ -337,6 +347,7 @@ int launch_paste_scan(rsx_engine* e, uint64_t count)
     const uint32_t ntiles = static_cast<uint32_t>(e->ntiles(count));
     const uint32_t ngroups = (ntiles + rsx::kScanTiles - 1) / rsx::kScanTiles;
     e->globsum_live = e->globsum2;
+    e->globsum_valid = true;
     Bracket b(e, PH_PASTE);
     hipLaunchKernelGGL(rsx::paste_scan_kernel, dim3(ngroups), dim3(rsx::kScanTiles), 0, e->stream, e->table, e->globsum, e->globsum2, e->temp,
                        ntiles, ngroups);
@@ -351,9 +362,14 @@ bool launch_scan_fused(rsx_engine* e, uint64_t count, bool from_counts, int* rc)
     const uint32_t ntiles = static_cast<uint32_t>(e->ntiles(count));
     const uint32_t ngroups = (ntiles + rsx::kScanTiles - 1) / rsx::kScanTiles;
     // (a captured graph would replay a stale epoch: the graph path keeps the separate launches)
-    if (!e->fused_scan || e->use_graph || count == 0 || ngroups > static_cast<uint32_t>(rsx::kFusedScanMaxGroups)) return false;
+    // every workgroup of the fused scan waits for every other one's group sums: the whole grid must be resident at once.
+    // fused_scan_limit is derived from the occupancy query at rsx_create (half of what the device holds, so that two
+    // engines scanning at the same time still fit); larger tables take scan #1, then scan #2 + paste (two launches).
+    if (!e->fused_scan || e->use_graph || count == 0 || ngroups > e->fused_scan_limit) return false;
     e->counted_keys = nullptr;
     e->globsum_live = e->globsum2;
+    e->table_valid = true;
+    e->globsum_valid = true;
     if (++e->scan_epoch == 0) e->scan_epoch = 1;
     {
         Bracket b(e, PH_SCAN);
@@ -379,6 +395,8 @@ bool launch_scan_small(rsx_engine* e, uint64_t count, bool from_counts, int* rc)
     const uint32_t ntiles = static_cast<uint32_t>(e->ntiles(count));
     if (!e->small_scan || count == 0 || ntiles > static_cast<uint32_t>(rsx::kSmallScanMaxTiles)) return false;
     e->counted_keys = nullptr;
+    e->table_valid = true;
+    e->globsum_valid = false;           // one workgroup scans the whole table: there are no group sums
     {
         Bracket b(e, PH_SCAN);
         if (from_counts && e->scan_zeroes) {
@@ -411,7 +429,8 @@ int launch_paste(rsx_engine* e, uint64_t count)
 template <typename Key, bool PAYLOAD, bool LOOKAHEAD, bool RANGED = false, int KPT = kKeysPerThread>
 int launch_reorder_t(rsx_engine* e, const void* in, void* out, const uint32_t* pin, uint32_t* pout, uint64_t count, int shift,
                      uint32_t mask, int next_shift, bool fold_paste, Key lo = Key{0}, Key mul = Key{0}, uint32_t nsplit = 0,
-                     rsx::SelfScanArgs self = rsx::SelfScanArgs{nullptr, nullptr, nullptr}, uint32_t* next_counts = nullptr)
+                     rsx::SelfScanArgs self = rsx::SelfScanArgs{nullptr, nullptr, nullptr}, uint32_t* next_counts = nullptr,
+                     rsx::PeerArgs peer = rsx::PeerArgs{nullptr, nullptr})
 {
     using L = rsx::ReorderLayout<Key, kTileThreads, KPT, (!RANGED && RSX_ALIAS_COUNTERS != 0)>;
     const Grid g = grid_for(e, count, kTileThreads * KPT);
@@ -427,7 +446,7 @@ int launch_reorder_t(rsx_engine* e, const void* in, void* out, const uint32_t* p
 #else
                        fold_paste ? static_cast<const uint32_t*>(e->globsum) : static_cast<const uint32_t*>(nullptr),
 #endif
-                       lo, mul, split_set<Key>(e, nsplit), self);
+                       lo, mul, split_set<Key>(e, nsplit), self, peer);
     RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
     return RSX_OK;
 }
@@ -539,6 +558,8 @@ int sort_tile_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext_p
     if (rc != RSX_OK) return rc;
     e->last_in = npasses > 1 ? before_last : in;
     e->last_shift = (e->last_pass - 1) * RSX_RADIX_BITS;
+    e->table_valid = true;
+    e->globsum_valid = true;
     e->result_external = e->final_keys_out != nullptr;
     if (e->final_keys_out) {
         e->result_keys = e->final_keys_out;
@@ -595,6 +616,9 @@ int sort_selfscan_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* e
         pin = pout;
         dst ^= 1;
     }
+    // (tiles of 1024 keys leave no table in the engine's own geometry; the 4096-key form writes it in its last pass — but no group sums)
+    e->table_valid = (KPT == kKeysPerThread);
+    e->globsum_valid = false;
     if (in == e->keys[0] || in == e->keys[1]) e->cur = (in == e->keys[0]) ? 0 : 1;
     e->result_external = e->final_keys_out != nullptr;
     if (e->final_keys_out) {
@@ -608,6 +632,34 @@ int sort_selfscan_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* e
 }
 
 #if RSX_TILE_THREADS == 256      // (the 8-bit kernels are written for 256-thread tiles: one thread per digit)
+// The 8-bit chain's tables, allocated on first use — by sort_chain BEFORE any stream capture begins (an allocation inside
+// hipStreamBeginCapture invalidates the capture) and by rsx_set_option(RSX_OPT_RADIX_BITS, 8).  A call that failed half-way
+// keeps what it got and the next one asks for the rest.
+template <typename Key>
+int ensure_radix8(rsx_engine* e)
+{
+    if (e->radix8_ready) return RSX_OK;
+    using L = rsx::Reorder8Layout<Key, kTileThreads, kKeysPerThread>;
+    const size_t rows = static_cast<size_t>(e->ntiles(e->capacity)) * rsx::kRadix8 * 4;
+    const size_t groups = ((e->ntiles(e->capacity) + rsx::kScan8Tiles - 1) / rsx::kScan8Tiles) * rsx::kRadix8 * 4;
+    if (!e->counts8) RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->counts8), rows), RSX_INITIALIZATION_FAILED);
+    if (!e->table8) RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->table8), rows), RSX_INITIALIZATION_FAILED);
+    if (!e->gsum8) RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->gsum8), groups), RSX_INITIALIZATION_FAILED);
+    if (!e->csum8) RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->csum8), rsx::kScan8MaxChunks * rsx::kRadix8 * 4), RSX_INITIALIZATION_FAILED);
+    if (!e->cbase8) RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->cbase8), rsx::kScan8MaxChunks * rsx::kRadix8 * 4), RSX_INITIALIZATION_FAILED);
+    RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L::BYTES)), RSX_INITIALIZATION_FAILED);
+    RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L::BYTES)), RSX_INITIALIZATION_FAILED);
+    constexpr int lds_v2k = static_cast<int>(rsx::Reorder8V2Layout<Key, kTileThreads, kKeysPerThread, false>::BYTES);
+    constexpr int lds_v2p = static_cast<int>(rsx::Reorder8V2Layout<Key, kTileThreads, kKeysPerThread, true>::BYTES);
+    RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8v2_kernel<Key, kTileThreads, kKeysPerThread, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_v2k),
+            RSX_INITIALIZATION_FAILED);
+    RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8v2_kernel<Key, kTileThreads, kKeysPerThread, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_v2p),
+            RSX_INITIALIZATION_FAILED);
+    e->radix8_ready = true;
+    return RSX_OK;
+}
 // 8-bit digits: per pass histogram8 -> scan8 (two launches) -> reorder8, half as many passes.  Taken by the sort
 // chain when RSX_OPT_RADIX_BITS is 8 and the pass range [first_pass, last_pass) — counted in 4-bit passes, as
 // everywhere in this API — covers whole bytes.
@@ -619,21 +671,7 @@ int sort8_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext
     const uint32_t ngroups = (g.ntiles + rsx::kScan8Tiles - 1) / rsx::kScan8Tiles;
     const uint32_t chunk_groups = std::max<uint32_t>(64u, (ngroups + rsx::kScan8MaxChunks - 1) / rsx::kScan8MaxChunks);
     const uint32_t nchunks = (ngroups + chunk_groups - 1) / chunk_groups;
-    if (!e->radix8_ready) {
-        // (allocated on first use; a call that failed half-way keeps what it got and the next one asks for the rest)
-        const size_t rows = static_cast<size_t>(e->ntiles(e->capacity)) * rsx::kRadix8 * 4;
-        const size_t groups = ((e->ntiles(e->capacity) + rsx::kScan8Tiles - 1) / rsx::kScan8Tiles) * rsx::kRadix8 * 4;
-        if (!e->counts8) RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->counts8), rows), RSX_INITIALIZATION_FAILED);
-        if (!e->table8) RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->table8), rows), RSX_INITIALIZATION_FAILED);
-        if (!e->gsum8) RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->gsum8), groups), RSX_INITIALIZATION_FAILED);
-        if (!e->csum8) RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->csum8), rsx::kScan8MaxChunks * rsx::kRadix8 * 4), RSX_INITIALIZATION_FAILED);
-        if (!e->cbase8) RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->cbase8), rsx::kScan8MaxChunks * rsx::kRadix8 * 4), RSX_INITIALIZATION_FAILED);
-        RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L::BYTES)), RSX_INITIALIZATION_FAILED);
-        RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L::BYTES)), RSX_INITIALIZATION_FAILED);
-        e->radix8_ready = true;
-    }
+    if (!e->radix8_ready) return fail(RSX_INITIALIZATION_FAILED, "sort8_chain_enqueue: the 8-bit tables were not allocated (ensure_radix8)");
     const void* in = ext_keys ? ext_keys : e->keys[e->cur];
     const uint32_t* pin = e->has_payload ? (ext_keys ? ext_perm : e->perm[e->cur]) : nullptr;
     int dst = ext_keys ? e->cur : (e->cur ^ 1);
@@ -665,13 +703,27 @@ int sort8_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext
         }
         {
             Bracket b(e, PH_REORDER);
-            if (e->has_payload) {
+            constexpr size_t lds_v2k = rsx::Reorder8V2Layout<Key, kTileThreads, kKeysPerThread, false>::BYTES;
+            constexpr size_t lds_v2p = rsx::Reorder8V2Layout<Key, kTileThreads, kKeysPerThread, true>::BYTES;
+            if (e->reorder8_version == 2) {
+                if (e->has_payload) {
+                    hipLaunchKernelGGL((rsx::reorder8v2_kernel<Key, kTileThreads, kKeysPerThread, true>), dim3(g.blocks), dim3(kTileThreads),
+                                       lds_v2p, e->stream,
+                                       static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->table8, e->gsum8, e->cbase8, chunk_groups,
+                                       count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip);
+                } else {
+                    hipLaunchKernelGGL((rsx::reorder8v2_kernel<Key, kTileThreads, kKeysPerThread, false>), dim3(g.blocks), dim3(kTileThreads),
+                                       lds_v2k, e->stream,
+                                       static_cast<const Key*>(in), static_cast<Key*>(out), nullptr, nullptr, e->table8, e->gsum8, e->cbase8, chunk_groups,
+                                       count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip);
+                }
+            } else if (e->has_payload) {
                 hipLaunchKernelGGL((rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, true>), dim3(g.blocks), dim3(kTileThreads), L::BYTES, e->stream,
-                                   static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->counts8, e->table8, e->gsum8, e->cbase8, chunk_groups,
+                                   static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->table8, e->gsum8, e->cbase8, chunk_groups,
                                    count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip);
             } else {
                 hipLaunchKernelGGL((rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, false>), dim3(g.blocks), dim3(kTileThreads), L::BYTES, e->stream,
-                                   static_cast<const Key*>(in), static_cast<Key*>(out), nullptr, nullptr, e->counts8, e->table8, e->gsum8, e->cbase8, chunk_groups,
+                                   static_cast<const Key*>(in), static_cast<Key*>(out), nullptr, nullptr, e->table8, e->gsum8, e->cbase8, chunk_groups,
                                    count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip);
             }
         }
@@ -682,6 +734,8 @@ int sort8_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext
         pin = pout;
         dst ^= 1;
     }
+    e->table_valid = false;             // the 8-bit tables are [tile][256]: nothing in the engine's [digit][tile] geometry
+    e->globsum_valid = false;
     if (in == e->keys[0] || in == e->keys[1]) e->cur = (in == e->keys[0]) ? 0 : 1;
     e->result_external = e->final_keys_out != nullptr;
     if (e->final_keys_out) {
@@ -801,6 +855,12 @@ constexpr uint64_t kGraphMaxKeys = 1ull << 22;
 template <typename Key>
 int sort_chain(rsx_engine* e, const void* ext_keys, const uint32_t* ext_perm, uint64_t count)
 {
+#if RSX_TILE_THREADS == 256
+    if (e->radix_bits == 8 && count > e->radix8_min_keys) {
+        const int rc8 = ensure_radix8<Key>(e);          // before any capture begins
+        if (rc8 != RSX_OK) return rc8;
+    }
+#endif
     // (the legacy null stream cannot be captured: PyTorch's default stream is that one)
     const bool graphable = e->use_graph && e->profile == 0 && count > 0 && count <= kGraphMaxKeys && e->stream != nullptr && !e->final_keys_out;
     if (!graphable) return sort_chain_enqueue<Key>(e, ext_keys, ext_perm, count);
@@ -857,12 +917,17 @@ int sort_chain(rsx_engine* e, const void* ext_keys, const uint32_t* ext_perm, ui
 }
 
 // a fused-scan workgroup whose poll ran out leaves a flag: surfaced at the host's next synchronisation point
+// (the flag is a word of mapped pinned host memory that the kernel stores to at system scope: reading it costs no copy and no
+// synchronisation, so it is also looked at by the asynchronous calls — there it reports a time-out of work that has already
+// finished; the synchronising calls look after their hipStreamSynchronize.)  Reported once, then cleared: the engine stays usable.
 int check_scan_timeout(rsx_engine* e, int status)
 {
-    if (e->scan_epoch == 0) return RSX_OK;
-    RSX_TRY(hipMemcpyAsync(e->scan_timeout_host, e->scan_timeout, 4, hipMemcpyDeviceToHost, e->stream), status);
-    RSX_TRY(hipStreamSynchronize(e->stream), status);
-    if (e->scan_timeout_host[0] != 0) return fail(status, "the fused table scan timed out waiting for a group sum (result undefined)");
+    if (!e->scan_timeout_host) return RSX_OK;
+    volatile uint32_t* flag = e->scan_timeout_host;
+    if (*flag != 0) {
+        *flag = 0;
+        return fail(status, "the fused table scan timed out waiting for a group sum: the result of that sort is undefined (reported once; the engine remains usable)");
+    }
     return RSX_OK;
 }
 bool aligned16(const void* p)
@@ -970,6 +1035,7 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
     if (const char* env = std::getenv("RSX_SMALL_TILE_MAX_KEYS")) e->small_tile_max_keys = std::min<uint64_t>(std::strtoull(env, nullptr, 10), static_cast<uint64_t>(rsx::kSelfScanMaxTiles) * kTileThreads * kSmallKeysPerThread);
     if (const char* env = std::getenv("RSX_SELF_SCAN_MAX")) e->self_scan_max = std::min<uint32_t>(static_cast<uint32_t>(std::atoi(env)), rsx::kSelfScanMaxTiles);
     if (const char* env = std::getenv("RSX_RADIX_BITS")) e->radix_bits = std::atoi(env) == 8 ? 8 : 4;
+    if (const char* env = std::getenv("RSX_REORDER8_V")) e->reorder8_version = std::atoi(env) == 1 ? 1 : 2;
     if (const char* env = std::getenv("RSX_RADIX8_MIN_KEYS")) e->radix8_min_keys = std::max<uint64_t>(std::strtoull(env, nullptr, 10), kTileKeys);
     if (const char* env = std::getenv("RSX_PASTE_SCAN")) e->paste_scan = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_FUSED_SCAN")) e->fused_scan = std::atoi(env) != 0;
@@ -1025,13 +1091,27 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
         return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(group sums)", err);
     if ((err = hipMemsetAsync(e->gsums, 0, rsx::kFusedScanMaxGroups * RSX_RADIX * 8, e->stream)) != hipSuccess)
         return bail(RSX_INITIALIZATION_FAILED, "hipMemsetAsync(group sums)", err);
-    if ((err = hipMalloc(reinterpret_cast<void**>(&e->scan_timeout), 64)) != hipSuccess)
-        return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(scan timeout flag)", err);
-    if ((err = hipMemsetAsync(e->scan_timeout, 0, 64, e->stream)) != hipSuccess)
-        return bail(RSX_INITIALIZATION_FAILED, "hipMemsetAsync(scan timeout flag)", err);
-    if ((err = hipHostMalloc(reinterpret_cast<void**>(&e->scan_timeout_host), 64, hipHostMallocDefault)) != hipSuccess)
+    if ((err = hipHostMalloc(reinterpret_cast<void**>(&e->scan_timeout_host), 64, hipHostMallocMapped)) != hipSuccess)
         return bail(RSX_HOST_BUFFERS_FAILED, "hipHostMalloc(scan timeout flag)", err);
     e->scan_timeout_host[0] = 0;
+    if ((err = hipHostGetDevicePointer(reinterpret_cast<void**>(&e->scan_timeout), e->scan_timeout_host, 0)) != hipSuccess)
+        return bail(RSX_HOST_BUFFERS_FAILED, "hipHostGetDevicePointer(scan timeout flag)", err);
+    {
+        // Co-residency of the fused scan: its workgroups wait for each other inside one launch, so a table may take it only
+        // if the device holds the whole grid at once.  The occupancy query is advisory (ROCm 7.2 over-reports by one
+        // workgroup per CU for SGPR-heavy kernels) and other work may hold CUs: half of its answer is the limit, which also
+        // leaves room for a second engine scanning on another stream.  On a partitioned device (CPX: 32 CUs) the same
+        // arithmetic gives a correspondingly smaller limit; RSX_OPT_FUSED_SCAN_MAX_GROUPS / env RSX_FUSED_SCAN_MAX_GROUPS override it.
+        int per_cu = 0, cus = 0;
+        if ((err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&rsx::scan_fused_kernel<true, true>), rsx::kScanTiles, 0)) != hipSuccess)
+            return bail(RSX_INITIALIZATION_FAILED, "hipOccupancyMaxActiveBlocksPerMultiprocessor(scan_fused_kernel)", err);
+        if ((err = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess)
+            return bail(RSX_INITIALIZATION_FAILED, "hipDeviceGetAttribute(multiProcessorCount)", err);
+        e->fused_scan_resident = static_cast<uint32_t>(std::max(per_cu, 0)) * static_cast<uint32_t>(std::max(cus, 0));
+        e->fused_scan_limit = std::min<uint32_t>(e->fused_scan_resident / 2, rsx::kFusedScanMaxGroups);
+        if (const char* env = std::getenv("RSX_FUSED_SCAN_MAX_GROUPS"))
+            e->fused_scan_limit = std::min<uint32_t>(static_cast<uint32_t>(std::max(0, std::atoi(env))), std::min<uint32_t>(e->fused_scan_resident, rsx::kFusedScanMaxGroups));
+    }
     if ((err = hipMalloc(reinterpret_cast<void**>(&e->ref_table), rsx::kRefTable * 4)) != hipSuccess)
         return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(ref table)", err);
     if ((err = hipMalloc(reinterpret_cast<void**>(&e->ref_globsum), rsx::kRefSplit * 4)) != hipSuccess)
@@ -1111,9 +1191,9 @@ int rsx_destroy(rsx_engine* e)
     if (e->gsum8 && hipFree(e->gsum8) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->csum8 && hipFree(e->csum8) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->cbase8 && hipFree(e->cbase8) != hipSuccess) status = RSX_CLEANUP_FAILED;
-    if (e->scan_timeout && hipFree(e->scan_timeout) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->scan_timeout_host && hipHostFree(e->scan_timeout_host) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->starts_dev && hipFree(e->starts_dev) != hipSuccess) status = RSX_CLEANUP_FAILED;
+    if (e->peer_dev && hipFree(e->peer_dev) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->range_dev && hipFree(e->range_dev) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->ref_table && hipFree(e->ref_table) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->ref_globsum && hipFree(e->ref_globsum) != hipSuccess) status = RSX_CLEANUP_FAILED;
@@ -1173,6 +1253,18 @@ int rsx_set_option(rsx_engine* e, int option, int64_t value)
     case RSX_OPT_SMALL_SCAN: e->small_scan = value != 0; return RSX_OK;
     case RSX_OPT_TILE_SORT: e->tile_sort = value != 0; return RSX_OK;
     case RSX_OPT_FUSED_SCAN: e->fused_scan = value != 0; return RSX_OK;
+    case RSX_OPT_FUSED_SCAN_MAX_GROUPS:
+        // never beyond what the occupancy query says is resident at once (nor the granule buffer): -1 restores the default
+        if (value < -1) return fail(RSX_CALCULATION_FAILED, "rsx_set_option: negative group count");
+        e->fused_scan_limit = value < 0 ? std::min<uint32_t>(e->fused_scan_resident / 2, rsx::kFusedScanMaxGroups)
+                                        : static_cast<uint32_t>(std::min<int64_t>(value, std::min<uint32_t>(e->fused_scan_resident, rsx::kFusedScanMaxGroups)));
+        return RSX_OK;
+    case RSX_OPT_DEBUG_RAISE_SCAN_TIMEOUT:
+        // tests only: stores to the time-out word exactly as a fused-scan workgroup whose poll ran out does
+        if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
+        hipLaunchKernelGGL(rsx::raise_flag_kernel, dim3(1), dim3(64), 0, e->stream, e->scan_timeout);
+        RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
+        return RSX_OK;
     case RSX_OPT_SELF_SCAN: e->self_scan = value != 0; return RSX_OK;
     case RSX_OPT_SMALL_TILE_MAX_KEYS:
         if (value < 0) return fail(RSX_CALCULATION_FAILED, "rsx_set_option: negative key count");
@@ -1189,6 +1281,12 @@ int rsx_set_option(rsx_engine* e, int option, int64_t value)
     case RSX_OPT_RADIX_BITS:
         if (value != 4 && value != 8) return fail(RSX_CALCULATION_FAILED, "rsx_set_option: digit width must be 4 or 8 bits");
         e->radix_bits = static_cast<int>(value);
+#if RSX_TILE_THREADS == 256
+        if (value == 8 && e->capacity > e->radix8_min_keys) {
+            if (bind_device(e, RSX_INITIALIZATION_FAILED) != RSX_OK) return RSX_INITIALIZATION_FAILED;
+            return RSX_BY_KEY(e, ensure_radix8<uint32_t>(e), ensure_radix8<uint64_t>(e));
+        }
+#endif
         return RSX_OK;
     case RSX_OPT_FIRST_PASS:
         if (value < 0 || value > e->passes()) return fail(RSX_CALCULATION_FAILED, "rsx_set_option: first pass out of range");
@@ -1216,6 +1314,8 @@ int rsx_get_geometry(const rsx_engine* e, rsx_geometry* out)
     out->num_scan_blocks = static_cast<uint64_t>(RSX_RADIX) * ((out->num_tiles + rsx::kScanTiles - 1) / rsx::kScanTiles);
     out->num_passes = e->passes();
     out->key_bytes = static_cast<uint32_t>(e->key_bytes);
+    out->fused_scan_resident = e->fused_scan_resident;
+    out->fused_scan_max_groups = e->fused_scan_limit;
     return RSX_OK;
 }
 
@@ -1278,6 +1378,7 @@ int rsx_download(rsx_engine* e, void* host_keys_out, uint32_t* host_perm_out, ui
 {
     if (!e) return fail(RSX_DATA_DOWNLOAD_FAILED, "rsx_download: null engine");
     if (bind_device(e, RSX_DATA_DOWNLOAD_FAILED) != RSX_OK) return RSX_DATA_DOWNLOAD_FAILED;
+    RSX_TRY(hipStreamSynchronize(e->stream), RSX_DATA_DOWNLOAD_FAILED);
     if (check_scan_timeout(e, RSX_DATA_DOWNLOAD_FAILED) != RSX_OK) return RSX_DATA_DOWNLOAD_FAILED;
     if (e->result_external && e->n > 0 && (host_keys_out || host_perm_out))
         return fail(RSX_DATA_DOWNLOAD_FAILED, "rsx_download: the last sort (rsx_sort_from_to) wrote into the caller's buffer; the engine holds no result");
@@ -1313,6 +1414,13 @@ int rsx_download(rsx_engine* e, void* host_keys_out, uint32_t* host_perm_out, ui
         RSX_TRY(hipStreamSynchronize(e->stream), RSX_DATA_DOWNLOAD_FAILED);
         return RSX_OK;
     }
+    // The engine's own table exists only after a pass in the 4096-key [digit][tile] geometry (the step API, the chains with scan
+    // launches, the 4096-key self-scan chain, the one-workgroup sort); sorts on 1024-key tiles and 8-bit passes leave none, and
+    // handing out what an earlier sort left would be silently wrong.  RSX_OPT_REF_DIAGNOSTICS rebuilds its tables for any path.
+    if (hist_out && hist_cap && e->n > 0 && !e->table_valid)
+        return fail(RSX_DATA_DOWNLOAD_FAILED, "rsx_download: the last sort left no table in the engine's [digit][tile] geometry (tiles of 1024 keys or 8-bit digits); use RSX_OPT_REF_DIAGNOSTICS, or RSX_OPT_SMALL_TILE_MAX_KEYS = 0 / 4-bit digits");
+    if (globsum_out && globsum_cap && e->n > 0 && !e->globsum_valid)
+        return fail(RSX_DATA_DOWNLOAD_FAILED, "rsx_download: the last sort's table scan produced no group sums (self-scan, one-workgroup scan or 8-bit digits); use RSX_OPT_REF_DIAGNOSTICS, or the chain with scan launches");
     if (hist_out && hist_cap) {
         const uint64_t live = static_cast<uint64_t>(RSX_RADIX) * e->ntiles(e->n);
         const uint64_t take = std::min(hist_cap, live);
@@ -1473,6 +1581,12 @@ int rsx_sync(rsx_engine* e)
     if (!e) return fail(RSX_CALCULATION_FAILED, "rsx_sync: null engine");
     if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
     RSX_TRY(hipStreamSynchronize(e->stream), RSX_CALCULATION_FAILED);
+    return check_scan_timeout(e, RSX_CALCULATION_FAILED);
+}
+
+int rsx_check_status(rsx_engine* e)
+{
+    if (!e) return fail(RSX_CALCULATION_FAILED, "rsx_check_status: null engine");
     return check_scan_timeout(e, RSX_CALCULATION_FAILED);
 }
 
@@ -1774,21 +1888,19 @@ int rsx_partition_count_waves_device(rsx_engine* e, const void* d_keys, uint64_t
     return RSX_OK;
 }
 
-int rsx_partition_scatter_waves(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n, void* d_keys_out, uint32_t* d_payload_out)
+namespace {
+// scan + paste + stable scatter of a wave-major count (rsx_partition_count_waves*): into the caller's one buffer, or — `peer` set —
+// bucket by bucket into 16 destination addresses
+int scatter_waves(rsx_engine* e, const char* who, const void* d_keys, const uint32_t* d_payload, uint64_t n, void* d_keys_out, uint32_t* d_payload_out,
+                  rsx::PeerArgs peer)
 {
-    if (!e) return fail(RSX_CALCULATION_FAILED, "rsx_partition_scatter_waves: null engine");
-    if (n == 0) {
-        e->counted_keys = nullptr;
-        return RSX_OK;
-    }
     if (d_keys != e->counted_keys || n != e->counted_n || e->counted_shift != -2)
-        return fail(RSX_CALCULATION_FAILED, "rsx_partition_scatter_waves: must follow rsx_partition_count_waves on the same keys");
+        return fail(RSX_CALCULATION_FAILED, (std::string(who) + ": must follow rsx_partition_count_waves on the same keys").c_str());
     e->counted_keys = nullptr;
-    if (!d_keys_out || !aligned16(d_keys_out)) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_partition_scatter_waves: output must be a 16-byte aligned device pointer");
-    const bool with_payload = e->has_payload && d_payload && d_payload_out;
-    if (e->has_payload && !with_payload) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_partition_scatter_waves: payload engine needs payload buffers");
-    if (with_payload && !aligned16(d_payload)) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_partition_scatter_waves: the payload input must be 16-byte aligned (it is read 16 bytes per lane)");
-    if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
+    if (!peer.keys && (!d_keys_out || !aligned16(d_keys_out))) return fail(RSX_HOST_BUFFERS_FAILED, (std::string(who) + ": output must be a 16-byte aligned device pointer").c_str());
+    const bool with_payload = e->has_payload && d_payload && (d_payload_out || peer.pays);
+    if (e->has_payload && !with_payload) return fail(RSX_HOST_BUFFERS_FAILED, (std::string(who) + ": payload engine needs payload buffers").c_str());
+    if (with_payload && !aligned16(d_payload)) return fail(RSX_HOST_BUFFERS_FAILED, (std::string(who) + ": the payload input must be 16-byte aligned (it is read 16 bytes per lane)").c_str());
     int rc = launch_scan(e, n);
     if (rc == RSX_OK) rc = launch_paste(e, n);
     if (rc != RSX_OK) return rc;
@@ -1796,15 +1908,119 @@ int rsx_partition_scatter_waves(rsx_engine* e, const void* d_keys, const uint32_
     uint32_t* pout = with_payload ? d_payload_out : nullptr;
     const int shift = e->key_bytes * 8 - RSX_RADIX_BITS;
     e->wave_rot = static_cast<uint32_t>(e->counted_bits % RSX_RADIX_BITS);
+    const rsx::SelfScanArgs none{nullptr, nullptr, nullptr};
     if (e->key_bytes == 4) {
-        rc = with_payload ? launch_reorder_t<uint32_t, true, false, true>(e, d_keys, d_keys_out, pin, pout, n, shift, RSX_RADIX - 1, 0, false, 0u, 0u, 0)
-                          : launch_reorder_t<uint32_t, false, false, true>(e, d_keys, d_keys_out, nullptr, nullptr, n, shift, RSX_RADIX - 1, 0, false, 0u, 0u, 0);
+        rc = with_payload ? launch_reorder_t<uint32_t, true, false, true>(e, d_keys, d_keys_out, pin, pout, n, shift, RSX_RADIX - 1, 0, false, 0u, 0u, 0, none, nullptr, peer)
+                          : launch_reorder_t<uint32_t, false, false, true>(e, d_keys, d_keys_out, nullptr, nullptr, n, shift, RSX_RADIX - 1, 0, false, 0u, 0u, 0, none, nullptr, peer);
     } else {
-        rc = with_payload ? launch_reorder_t<uint64_t, true, false, true>(e, d_keys, d_keys_out, pin, pout, n, shift, RSX_RADIX - 1, 0, false, 0ull, 0ull, 0)
-                          : launch_reorder_t<uint64_t, false, false, true>(e, d_keys, d_keys_out, nullptr, nullptr, n, shift, RSX_RADIX - 1, 0, false, 0ull, 0ull, 0);
+        rc = with_payload ? launch_reorder_t<uint64_t, true, false, true>(e, d_keys, d_keys_out, pin, pout, n, shift, RSX_RADIX - 1, 0, false, 0ull, 0ull, 0, none, nullptr, peer)
+                          : launch_reorder_t<uint64_t, false, false, true>(e, d_keys, d_keys_out, nullptr, nullptr, n, shift, RSX_RADIX - 1, 0, false, 0ull, 0ull, 0, none, nullptr, peer);
     }
     e->wave_rot = 0;
     return rc;
+}
+}  // namespace
+
+int rsx_partition_scatter_waves(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n, void* d_keys_out, uint32_t* d_payload_out)
+{
+    if (!e) return fail(RSX_CALCULATION_FAILED, "rsx_partition_scatter_waves: null engine");
+    if (n == 0) {
+        e->counted_keys = nullptr;
+        return RSX_OK;
+    }
+    if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
+    return scatter_waves(e, "rsx_partition_scatter_waves", d_keys, d_payload, n, d_keys_out, d_payload_out, rsx::PeerArgs{nullptr, nullptr});
+}
+
+int rsx_partition_scatter_waves_peer(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n, void* const* peer_keys, uint32_t* const* peer_payload)
+{
+    if (!e || !peer_keys) return fail(RSX_CALCULATION_FAILED, "rsx_partition_scatter_waves_peer: null argument");
+    if (e->has_payload && !peer_payload) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_partition_scatter_waves_peer: payload engine needs payload destinations");
+    if (n == 0) {
+        e->counted_keys = nullptr;
+        return RSX_OK;
+    }
+    if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
+    if (!e->peer_dev) RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->peer_dev), 2 * RSX_RADIX * 8), RSX_INITIALIZATION_FAILED);
+    // (from pageable memory: the runtime has captured the 256 bytes when the call returns, so the array may live on this stack)
+    unsigned long long addr[2 * RSX_RADIX] = {};
+    for (int b = 0; b < RSX_RADIX; ++b) {
+        addr[b] = reinterpret_cast<unsigned long long>(peer_keys[b]);
+        addr[RSX_RADIX + b] = e->has_payload ? reinterpret_cast<unsigned long long>(peer_payload[b]) : 0ull;
+        const bool needed = true;       // a bucket without keys is never dereferenced, but a null address for one that has keys would fault: refuse all nulls
+        if (needed && (!addr[b] || (e->has_payload && !addr[RSX_RADIX + b])))
+            return fail(RSX_HOST_BUFFERS_FAILED, "rsx_partition_scatter_waves_peer: null destination address");
+        if (addr[b] % static_cast<unsigned>(e->key_bytes) || addr[RSX_RADIX + b] % 4u)
+            return fail(RSX_HOST_BUFFERS_FAILED, "rsx_partition_scatter_waves_peer: misaligned destination address");
+    }
+    RSX_TRY(hipMemcpyAsync(e->peer_dev, addr, sizeof(addr), hipMemcpyHostToDevice, e->stream), RSX_CALCULATION_FAILED);
+    return scatter_waves(e, "rsx_partition_scatter_waves_peer", d_keys, d_payload, n, nullptr, nullptr,
+                         rsx::PeerArgs{e->peer_dev, e->has_payload ? e->peer_dev + RSX_RADIX : nullptr});
+}
+
+// ---- peer-visible buffers (the receive side of the peer-store exchange) ----------------------------------------------------
+int rsx_peer_alloc(rsx_engine* e, uint64_t bytes, void** d_ptr, void* ipc_handle)
+{
+    if (!e || !d_ptr || bytes == 0) return fail(RSX_INITIALIZATION_FAILED, "rsx_peer_alloc: null argument");
+    if (bind_device(e, RSX_INITIALIZATION_FAILED) != RSX_OK) return RSX_INITIALIZATION_FAILED;
+    *d_ptr = nullptr;
+    void* p = nullptr;
+    RSX_TRY(hipMalloc(&p, static_cast<size_t>(bytes)), RSX_INITIALIZATION_FAILED);
+    if (ipc_handle) {
+        static_assert(sizeof(hipIpcMemHandle_t) == RSX_IPC_HANDLE_BYTES, "handle size of the C ABI");
+        hipIpcMemHandle_t h;
+        const hipError_t err = hipIpcGetMemHandle(&h, p);
+        if (err != hipSuccess) {
+            (void)hipFree(p);
+            return fail(RSX_INITIALIZATION_FAILED, "hipIpcGetMemHandle", err);
+        }
+        std::memcpy(ipc_handle, &h, sizeof(h));
+    }
+    *d_ptr = p;
+    return RSX_OK;
+}
+
+int rsx_peer_free(rsx_engine* e, void* d_ptr)
+{
+    if (!e) return fail(RSX_CLEANUP_FAILED, "rsx_peer_free: null engine");
+    if (!d_ptr) return RSX_OK;
+    if (bind_device(e, RSX_CLEANUP_FAILED) != RSX_OK) return RSX_CLEANUP_FAILED;
+    RSX_TRY(hipFree(d_ptr), RSX_CLEANUP_FAILED);
+    return RSX_OK;
+}
+
+int rsx_peer_open(rsx_engine* e, const void* ipc_handle, void** d_ptr)
+{
+    if (!e || !ipc_handle || !d_ptr) return fail(RSX_INITIALIZATION_FAILED, "rsx_peer_open: null argument");
+    if (bind_device(e, RSX_INITIALIZATION_FAILED) != RSX_OK) return RSX_INITIALIZATION_FAILED;
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, ipc_handle, sizeof(h));
+    *d_ptr = nullptr;
+    RSX_TRY(hipIpcOpenMemHandle(d_ptr, h, hipIpcMemLazyEnablePeerAccess), RSX_INITIALIZATION_FAILED);
+    return RSX_OK;
+}
+
+int rsx_peer_close(rsx_engine* e, void* d_ptr)
+{
+    if (!e) return fail(RSX_CLEANUP_FAILED, "rsx_peer_close: null engine");
+    if (!d_ptr) return RSX_OK;
+    if (bind_device(e, RSX_CLEANUP_FAILED) != RSX_OK) return RSX_CLEANUP_FAILED;
+    RSX_TRY(hipIpcCloseMemHandle(d_ptr), RSX_CLEANUP_FAILED);
+    return RSX_OK;
+}
+
+int rsx_peer_enable(rsx_engine* e, int peer_device)
+{
+    if (!e) return fail(RSX_INITIALIZATION_FAILED, "rsx_peer_enable: null engine");
+    if (peer_device == e->device) return RSX_OK;
+    if (bind_device(e, RSX_INITIALIZATION_FAILED) != RSX_OK) return RSX_INITIALIZATION_FAILED;
+    int can = 0;
+    RSX_TRY(hipDeviceCanAccessPeer(&can, e->device, peer_device), RSX_INITIALIZATION_FAILED);
+    if (!can) return fail(RSX_INITIALIZATION_FAILED, "rsx_peer_enable: the device cannot access that peer");
+    const hipError_t err = hipDeviceEnablePeerAccess(peer_device, 0);
+    if (err != hipSuccess && err != hipErrorPeerAccessAlreadyEnabled) return fail(RSX_INITIALIZATION_FAILED, "hipDeviceEnablePeerAccess", err);
+    (void)hipGetLastError();
+    return RSX_OK;
 }
 
 int rsx_key_range(rsx_engine* e, const void* d_keys, uint64_t n, uint64_t* lo, uint64_t* hi)
@@ -1876,6 +2092,7 @@ int rsx_copy_result(rsx_engine* e, void* d_keys_out, uint32_t* d_payload_out)
     if (!e) return fail(RSX_DATA_DOWNLOAD_FAILED, "rsx_copy_result: null engine");
     if (bind_device(e, RSX_DATA_DOWNLOAD_FAILED) != RSX_OK) return RSX_DATA_DOWNLOAD_FAILED;
     if (e->n == 0) return RSX_OK;
+    if (check_scan_timeout(e, RSX_DATA_DOWNLOAD_FAILED) != RSX_OK) return RSX_DATA_DOWNLOAD_FAILED;      // (of sorts that have finished: this call does not synchronise)
     if (e->result_external)
         return fail(RSX_DATA_DOWNLOAD_FAILED, "rsx_copy_result: the last sort (rsx_sort_from_to) wrote into the caller's buffer; the engine holds no result");
     if (d_keys_out) {

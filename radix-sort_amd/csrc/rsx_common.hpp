@@ -146,8 +146,9 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
 }
 
 // Exclusive prefix over the workgroup of one value per thread; `total` gets the sum.
-// `wtot` is LDS scratch of THREADS/64 words.  Contains two barriers.
-template <int THREADS>
+// `wtot` is LDS scratch of THREADS/64 words.  Contains two barriers; TRAILING_BARRIER = false drops the second one for callers
+// that do not touch `wtot` again before their own next barrier.
+template <int THREADS, bool TRAILING_BARRIER = true>
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* wtot, uint32_t& total)
 {
     constexpr int WAVES = THREADS / kWave;
@@ -166,7 +167,9 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* w
         all += t;
     }
     total = all;
-    __syncthreads();   // wtot may be reused by the caller
+    if constexpr (TRAILING_BARRIER) {
+        __syncthreads();   // wtot may be reused by the caller
+    }
     return before + incl - v;
 }
 

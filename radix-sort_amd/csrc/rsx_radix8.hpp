@@ -15,11 +15,14 @@ namespace rsx {
 // sorted locally by the low nibble and then by the high nibble of the digit — two stable rounds through LDS, the
 // second one starting from 16 consecutive keys of the first one's order per thread — and leaves as up to 256 runs.
 // Tables are [tile][256] (a tile's 256 counters are one contiguous 1 KiB row):
-//   histogram8_kernel   counts8[tile][d]   = keys of the tile with digit d
-//   scan8_blocks_kernel table8[tile][d]    = keys with digit d in EARLIER tiles of the tile's group (G tiles); gsum8[group][d] = group total
+//   histogram8_kernel   counts8[tile][d]   = (keys of the tile with digit d) | (keys of the tile with a SMALLER digit) << 16   — both <= 4096
+//   scan8_blocks_kernel table8[tile][d]    = (keys with digit d in EARLIER tiles of the tile's group of G tiles) - (keys of the tile with a smaller digit);
+//                                            gsum8[group][d] = group total
 //   scan8_chunks_kernel gsum8[group][d]    = keys with digit d in earlier groups of the group's chunk; csum8[chunk][d] = chunk total
-//   reorder8_kernel     slot of a key      = (keys with smaller digits) + (digit d in earlier chunks) + gsum8[group][d] + table8[tile][d]
-//                                            + (its rank inside the tile's run of digit d)
+//   reorder8_kernel     slot of a key      = cbase8[chunk][d] (keys with smaller digits + digit d in earlier chunks) + gsum8[group][d] + table8[tile][d]
+//                                            + (its slot in the tile-local sorted order)
+// (round 3: the tile's own exclusive scan over its 256 counts is done once, by the histogram kernel, which has the counts in LDS anyway, and rides
+// in the upper half of the count word — the scatter kernel then needs one table row instead of two, no block scan and two barriers fewer.)
 constexpr int kRadix8 = 256;
 constexpr int kScan8Tiles = 64;               // tiles per scan group
 
@@ -38,6 +41,7 @@ __global__ __launch_bounds__(THREADS) void histogram8_kernel(const Key* __restri
     constexpr int VEC = KeyVec<Key>::N;
     constexpr int NV = KPT / VEC;
     __shared__ uint32_t cnt[kRadix8];
+    __shared__ uint32_t wtot[kRadix8 / kWave];
     const uint32_t tid = threadIdx.x;
     const uint32_t tile = tile_of_block(blockIdx.x, tiles_per_xcd, remap);
     if (tile >= ntiles) {
@@ -90,7 +94,12 @@ __global__ __launch_bounds__(THREADS) void histogram8_kernel(const Key* __restri
         }
     }
     __syncthreads();
-    counts8[static_cast<uint64_t>(tile) * kRadix8 + tid] = cnt[tid];
+    {
+        const uint32_t c = cnt[tid];
+        uint32_t all;
+        const uint32_t local_first = block_exclusive_scan<THREADS, false>(c, wtot, all);       // keys of the tile with a smaller digit
+        counts8[static_cast<uint64_t>(tile) * kRadix8 + tid] = c | (local_first << 16);
+    }
 }
 
 // one workgroup per group of kScan8Tiles tiles; thread d walks the group's rows (1 KiB each, coalesced)
@@ -110,14 +119,15 @@ __global__ __launch_bounds__(kRadix8) void scan8_blocks_kernel(const uint32_t* _
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            table8[static_cast<uint64_t>(t + u) * kRadix8 + d] = run;
-            run += c[u];
+            // word = count | (keys of the tile with a smaller digit) << 16: the entry is what the scatter adds to a key's tile-local slot
+            table8[static_cast<uint64_t>(t + u) * kRadix8 + d] = run - (c[u] >> 16);
+            run += c[u] & 0xFFFFu;
         }
     }
     for (; t < t1; ++t) {
         const uint32_t c = counts8[static_cast<uint64_t>(t) * kRadix8 + d];
-        table8[static_cast<uint64_t>(t) * kRadix8 + d] = run;
-        run += c;
+        table8[static_cast<uint64_t>(t) * kRadix8 + d] = run - (c >> 16);
+        run += c & 0xFFFFu;
     }
     gsum8[static_cast<uint64_t>(group) * kRadix8 + d] = run;
 }
@@ -209,7 +219,7 @@ struct Reorder8Layout {
 template <typename Key, int THREADS, int KPT, bool PAYLOAD>
 __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREADS, KPT>::MIN_WAVES > 4 ? 4 : Reorder8Layout<Key, THREADS, KPT>::MIN_WAVES))) void reorder8_kernel(
     const Key* __restrict__ in, Key* __restrict__ out, const uint32_t* __restrict__ pin, uint32_t* __restrict__ pout,
-    const uint32_t* __restrict__ counts8, const uint32_t* __restrict__ table8, const uint32_t* __restrict__ gsum8, const uint32_t* __restrict__ cbase8,
+    const uint32_t* __restrict__ table8, const uint32_t* __restrict__ gsum8, const uint32_t* __restrict__ cbase8,
     uint32_t chunk_groups, uint64_t n, uint32_t ntiles, uint32_t tiles_per_xcd, int remap, int shift, Key flip)
 {
     using L = Reorder8Layout<Key, THREADS, KPT>;
@@ -241,11 +251,11 @@ __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREAD
     const bool hi = sizeof(Key) == 8 && shift >= 32;      // the byte never straddles the halves of a 64-bit key
     const uint32_t sh = static_cast<uint32_t>(shift) & 31u;
 
-    // this thread's digit of the tile's table row (latency hides under the key loads)
-    const uint32_t my_count = counts8[static_cast<uint64_t>(tile) * kRadix8 + tid];
+    // this thread's digit of the tile's table row (latency hides under the key loads): global slot of the tile's first key with
+    // that digit minus its tile-local slot
     const uint32_t group = tile / kScan8Tiles;
-    const uint32_t my_first = table8[static_cast<uint64_t>(tile) * kRadix8 + tid] + gsum8[static_cast<uint64_t>(group) * kRadix8 + tid] +
-                              cbase8[static_cast<uint64_t>(group / chunk_groups) * kRadix8 + tid];      // smaller digits + this digit in earlier chunks
+    const uint32_t my_base = table8[static_cast<uint64_t>(tile) * kRadix8 + tid] + gsum8[static_cast<uint64_t>(group) * kRadix8 + tid] +
+                             cbase8[static_cast<uint64_t>(group / chunk_groups) * kRadix8 + tid];      // smaller digits + this digit in earlier chunks
 
     Key k[KPT];
     uint32_t pl[PAYLOAD ? KPT : 1];
@@ -284,20 +294,24 @@ __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREAD
             }
         }
     }
-    // local first slot of every digit = exclusive scan of the tile's 256 counts; gb = global first - local first
-    {
-        uint32_t all;
-        const uint32_t local_first = block_exclusive_scan<THREADS>(my_count, wtot, all);
-        gb[tid] = my_first - local_first;
-    }
+    gb[tid] = my_base;           // (read after several barriers)
     u32_alias* cnt32 = reinterpret_cast<u32_alias*>(cnt);
     unsigned char* cbytes = reinterpret_cast<unsigned char*>(cnt);
     // image: slot s at dword s*KD + 4*(s/16) (rows of KPT keys + 16 bytes); slot i = r*THREADS + tid -> per-thread base + r * OUT_STRIDE
     constexpr uint32_t OUT_STRIDE_DW = THREADS * KD + (THREADS / 16) * 4;
     const uint32_t out_base_dw = tid * KD + ((tid >> 4) << 2);
 
+#ifndef RSX_R8_PADDED_FINAL
+#define RSX_R8_PADDED_FINAL 0      // 1: the second round stages into reorder_kernel's padded image (slot + slot >> PADSH) instead of 16-key rows; both rounds unrolled
+#endif
+    constexpr int PADSH = (KD == 1) ? 5 : 4;
+#if RSX_R8_PADDED_FINAL
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
     for (int round = 0; round < 2; ++round) {
+        const bool padded = RSX_R8_PADDED_FINAL && round == 1;
         const uint32_t rsh = sh + static_cast<uint32_t>(round) * kRadixBits;      // sh is a multiple of 8: rsh + 4 <= 32
         uint32_t slot[KPT];
         {
@@ -327,7 +341,7 @@ __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREAD
             U32x4 b = *reinterpret_cast<const U32x4*>(cnt + tid * 8 + 4);
             const uint32_t sum = a.v[0] + a.v[1] + a.v[2] + a.v[3] + b.v[0] + b.v[1] + b.v[2] + b.v[3];
             uint32_t total;
-            uint32_t run = block_exclusive_scan<THREADS>(sum, wtot, total);
+            uint32_t run = block_exclusive_scan<THREADS, false>(sum, wtot, total);       // (wtot is next written two barriers on)
             run += total << 16;
             uint32_t t;
             t = a.v[0]; a.v[0] = run; run += t;
@@ -358,7 +372,9 @@ __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREAD
 #pragma unroll
             for (int i = 0; i < KPT; ++i) {
                 // byte offset of slot s: (s*KD + 4*(s>>4)) * 4
-                if constexpr (KD == 1) {
+                if (padded) {
+                    lds_store_at<Key>(add_lshl<(KD == 1 ? 2 : 3)>(slot[i], slot[i] >> PADSH), k[i]);
+                } else if constexpr (KD == 1) {
                     lds_store_at<Key>(add_lshl<2>(slot[i], (slot[i] >> 2) & ~3u), k[i]);
                 } else {
                     lds_store_at<Key>(add_lshl<2>(slot[i] << 1, (slot[i] >> 2) & ~3u), k[i]);
@@ -380,7 +396,11 @@ __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREAD
             Key okey[KPT];
 #pragma unroll
             for (int r = 0; r < KPT; ++r) {
-                okey[r] = *reinterpret_cast<const Key*>(xbuf + out_base_dw + static_cast<uint32_t>(r) * OUT_STRIDE_DW);
+                if (padded) {
+                    okey[r] = reinterpret_cast<const Key*>(xbuf)[tid + (tid >> PADSH) + static_cast<uint32_t>(r) * (THREADS + (THREADS >> PADSH))];
+                } else {
+                    okey[r] = *reinterpret_cast<const Key*>(xbuf + out_base_dw + static_cast<uint32_t>(r) * OUT_STRIDE_DW);
+                }
             }
             uint32_t g[KPT];
 #pragma unroll
@@ -415,7 +435,11 @@ __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREAD
             __syncthreads();           // every thread has taken its keys: the image carries the payload now
 #pragma unroll
             for (int i = 0; i < KPT; ++i) {
-                lds_store_at<uint32_t>(add_lshl<2>(slot[i], (slot[i] >> 2) & ~3u), pl[i]);
+                if (padded) {
+                    lds_store_at<uint32_t>(add_lshl<2>(slot[i], slot[i] >> 5), pl[i]);
+                } else {
+                    lds_store_at<uint32_t>(add_lshl<2>(slot[i], (slot[i] >> 2) & ~3u), pl[i]);
+                }
             }
             __syncthreads();
             if (round == 0) {
@@ -428,16 +452,297 @@ __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREAD
                     pl[q * 4 + 3] = x.v[3];
                 }
             } else {
-                const uint32_t pbase = tid + ((tid >> 4) << 2);
+                const uint32_t pbase = padded ? tid + (tid >> 5) : tid + ((tid >> 4) << 2);
+                const uint32_t pstride = padded ? THREADS + (THREADS >> 5) : THREADS + (THREADS / 16) * 4;
 #pragma unroll
                 for (int r = 0; r < KPT; ++r) {
                     if (full || static_cast<uint32_t>(r) * THREADS + tid < valid) {
-                        pout[static_cast<uint32_t>(k[r])] = xbuf[pbase + static_cast<uint32_t>(r) * (THREADS + (THREADS / 16) * 4)];
+                        pout[static_cast<uint32_t>(k[r])] = xbuf[pbase + static_cast<uint32_t>(r) * pstride];
                     }
                 }
             }
         }
         __syncthreads();               // image and counters are free for the second round
+    }
+}
+
+// ---------------------------------------------------------------------------
+// reorder8 v2 (round 3): the keys make ONE trip through LDS instead of two
+// ---------------------------------------------------------------------------
+// v1 above sorts the tile by the low nibble, stages it, re-reads it as 16 consecutive slots per thread, sorts by the high nibble
+// and stages it again — and with a payload every staging is followed by a second trip of the payload through the same image
+// (18 workgroup barriers per tile).  Here keys and payload stay in the registers of the thread that loaded them until the
+// final slot of every key is known:
+//   round 0  thread t ranks its 16 keys by the LOW nibble (nibble counters in a 64-bit register, packed words, raking scan: the
+//            4-bit machinery) -> s0 = slot in the order (low nibble, index); it leaves the key's HIGH nibble (<< 2, one byte) at H[s0]
+//   round 1  thread t owns slots 16t .. 16t+15 of that order: one ds_read_b128 of H gives their 16 high nibbles, which it ranks the
+//            same way -> s1 = slot in the order (high nibble, low nibble, index) = the tile-local sorted order; M[16t + j] = s1
+//            (16 x u16 = two ds_write_b128)
+//   final    the loading thread reads f = M[s0] for its 16 keys and stages key (and payload, into a second image, in the SAME trip)
+//            at f; the tile leaves as runs exactly as in reorder_kernel (padded image, per-thread read base + constant offsets).
+// Per key 1 byte + 2 bytes of hand-off instead of a whole second trip of key and payload; 10 barriers per tile with or without a
+// payload.  The work area (packed counters 8 KiB, H 4 KiB, M 8 KiB) is dead when the image is written and shares its LDS.
+template <typename Key, int THREADS, int KPT, bool PAYLOAD>
+struct Reorder8V2Layout {
+    static constexpr int TILE = THREADS * KPT;
+    static constexpr int KD = sizeof(Key) / 4;
+    static constexpr int PADSH = (KD == 1) ? 5 : 4;                      // as ReorderLayout: one pad element every 2^PADSH
+    static constexpr int XBUF_DW = (TILE + (TILE >> PADSH)) * KD;        // key image
+    static constexpr int PBUF_DW = PAYLOAD ? TILE + (TILE >> 5) : 0;     // payload image
+    static constexpr int IMAGE_DW = XBUF_DW + PBUF_DW;
+    static constexpr int CNT_DW = 8 * THREADS;
+    static constexpr int H_DW = TILE / 4;                                // one byte per slot
+    static constexpr int M_DW = TILE / 2;                                // one u16 per slot
+    static constexpr int CNT_AT = 0, H_AT = CNT_DW, M_AT = CNT_DW + H_DW;
+    static constexpr int WORK_DW = CNT_DW + H_DW + M_DW;
+    static constexpr int BODY_DW = IMAGE_DW > WORK_DW ? IMAGE_DW : WORK_DW;
+    static constexpr int TOTAL_DW = BODY_DW + 16 + kRadix8;              // + wave totals + run bases
+    static constexpr size_t BYTES = static_cast<size_t>(TOTAL_DW) * 4;
+    static constexpr int WGS_PER_CU = static_cast<int>((160 * 1024) / BYTES);
+#ifndef RSX_REORDER8_WAVES_CAP
+#define RSX_REORDER8_WAVES_CAP 5      // 6 (80 VGPRs) spills 12 bytes per lane in the uint32 keys-only kernel
+#endif
+    static constexpr int MIN_WAVES = (WGS_PER_CU * THREADS / 256) > RSX_REORDER8_WAVES_CAP ? RSX_REORDER8_WAVES_CAP : (WGS_PER_CU * THREADS / 256);
+    static_assert(KPT == 16 && THREADS == kRadix8, "16 slots per thread = one 16-byte row of H; one thread per digit handles the tile's table row");
+    static_assert((H_AT * 4) % 16 == 0 && (M_AT * 4) % 16 == 0 && (XBUF_DW * 4) % 16 == 0, "16-byte aligned rows");
+};
+
+template <typename Key, int THREADS, int KPT, bool PAYLOAD>
+__global__ __launch_bounds__(THREADS, (Reorder8V2Layout<Key, THREADS, KPT, PAYLOAD>::MIN_WAVES)) void reorder8v2_kernel(
+    const Key* __restrict__ in, Key* __restrict__ out, const uint32_t* __restrict__ pin, uint32_t* __restrict__ pout,
+    const uint32_t* __restrict__ table8, const uint32_t* __restrict__ gsum8, const uint32_t* __restrict__ cbase8,
+    uint32_t chunk_groups, uint64_t n, uint32_t ntiles, uint32_t tiles_per_xcd, int remap, int shift, Key flip)
+{
+    using L = Reorder8V2Layout<Key, THREADS, KPT, PAYLOAD>;
+    constexpr int TILE = L::TILE;
+    constexpr int VEC = KeyVec<Key>::N;
+    constexpr int NV = KPT / VEC;
+    constexpr uint32_t CNT_ROW_BYTES = THREADS * 4;
+    constexpr uint32_t H_BYTES = L::H_AT * 4, M_BYTES = L::M_AT * 4, PBUF_BYTES = L::XBUF_DW * 4;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t* cnt = smem + L::CNT_AT;
+    uint32_t* wtot = smem + L::BODY_DW;
+    uint32_t* gb = wtot + 16;                     // per 8-bit digit: (global slot of the tile's first key with it) - (its tile-local slot)
+    const uint32_t tid = threadIdx.x;
+    const uint32_t tile = tile_of_block(blockIdx.x, tiles_per_xcd, remap & ~2);
+    if (tile >= ntiles) {
+        return;
+    }
+    if (!lds_base_is_zero(smem)) {
+        __builtin_trap();           // lds_store_at addresses the work area and the image from LDS address 0
+    }
+    const uint64_t base = static_cast<uint64_t>(tile) * TILE;
+    const uint64_t left = n - base;
+    const uint32_t valid = left < static_cast<uint64_t>(TILE) ? static_cast<uint32_t>(left) : static_cast<uint32_t>(TILE);
+    const bool full = (valid == TILE);
+    // keys are held with the sign bit flipped (unsigned order = numeric order): digits are plain bit fields
+    const Key pad_key = static_cast<Key>(~Key{0});        // digit 255, behind every real key of the tile
+    const bool hi = sizeof(Key) == 8 && shift >= 32;      // the byte never straddles the halves of a 64-bit key
+    const uint32_t sh = static_cast<uint32_t>(shift) & 31u;
+
+    // this thread's digit of the tile's table row (latency hides under the key loads)
+    const uint32_t group = tile / kScan8Tiles;
+    const uint32_t my_base = table8[static_cast<uint64_t>(tile) * kRadix8 + tid] + gsum8[static_cast<uint64_t>(group) * kRadix8 + tid] +
+                             cbase8[static_cast<uint64_t>(group / chunk_groups) * kRadix8 + tid];
+
+    Key k[KPT];
+    uint32_t pl[PAYLOAD ? KPT : 1];
+    if (full) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const KeyVec<Key> v = load_keys16(in + base + tid * KPT + j * VEC);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                k[j * VEC + e] = v.k[e];
+            }
+        }
+        if constexpr (PAYLOAD) {
+#pragma unroll
+            for (int q = 0; q < KPT / 4; ++q) {
+                const U32x4 x = *reinterpret_cast<const U32x4*>(pin + base + tid * KPT + q * 4);
+                pl[q * 4 + 0] = x.v[0];
+                pl[q * 4 + 1] = x.v[1];
+                pl[q * 4 + 2] = x.v[2];
+                pl[q * 4 + 3] = x.v[3];
+            }
+        }
+        if (flip != Key{0}) {
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                k[i] ^= flip;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const uint32_t li = tid * KPT + i;
+            k[i] = li < valid ? static_cast<Key>(in[base + li] ^ flip) : pad_key;
+            if constexpr (PAYLOAD) {
+                pl[i] = li < valid ? pin[base + li] : 0u;
+            }
+        }
+    }
+    gb[tid] = my_base;           // (read after several barriers)
+    u32_alias* cnt32 = reinterpret_cast<u32_alias*>(cnt);
+    unsigned char* cbytes = reinterpret_cast<unsigned char*>(cnt);
+
+    // One ranking round of the 4-bit machinery over 16 values per thread given as `x4[i]` = digit << 2 (0 .. 60): on return
+    // slot[i] = position of (thread, i) in the workgroup-wide order (digit, thread, i).  Three barriers.
+    auto rank_round = [&](const uint32_t (&x4)[KPT], uint32_t (&slot)[KPT]) {
+        uint64_t seen = 0;
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            slot[i] = static_cast<uint32_t>(seen >> x4[i]) & 15u;
+#if RSX_EARLY_RANK
+            asm volatile("" : "+v"(slot[i]));
+#endif
+            if (i + 1 < KPT) {
+                seen += 1ull << x4[i];
+            }
+        }
+        const uint32_t seen_lo = static_cast<uint32_t>(seen), seen_hi = static_cast<uint32_t>(seen >> 32);
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+            cnt32[l * THREADS + tid] = __builtin_amdgcn_ubfe(seen_lo, 4u * l, 4u) | (__builtin_amdgcn_ubfe(seen_hi, 4u * l, 4u) << 16);
+        }
+        const uint32_t d_last = x4[KPT - 1] >> 2;
+        atomicAdd(cnt + (d_last & 7u) * THREADS + tid, 1u << ((d_last >> 3) * 16u));
+        __syncthreads();
+        {
+            U32x4 a = *reinterpret_cast<const U32x4*>(cnt + tid * 8);
+            U32x4 b = *reinterpret_cast<const U32x4*>(cnt + tid * 8 + 4);
+            const uint32_t sum = a.v[0] + a.v[1] + a.v[2] + a.v[3] + b.v[0] + b.v[1] + b.v[2] + b.v[3];
+            uint32_t total;
+            uint32_t run = block_exclusive_scan<THREADS, false>(sum, wtot, total);       // (wtot is next written several barriers on)
+            run += total << 16;
+            uint32_t t;
+            t = a.v[0]; a.v[0] = run; run += t;
+            t = a.v[1]; a.v[1] = run; run += t;
+            t = a.v[2]; a.v[2] = run; run += t;
+            t = a.v[3]; a.v[3] = run; run += t;
+            t = b.v[0]; b.v[0] = run; run += t;
+            t = b.v[1]; b.v[1] = run; run += t;
+            t = b.v[2]; b.v[2] = run; run += t;
+            t = b.v[3]; b.v[3] = run;
+            *reinterpret_cast<U32x4*>(cnt + tid * 8) = a;
+            *reinterpret_cast<U32x4*>(cnt + tid * 8 + 4) = b;
+        }
+        __syncthreads();
+        uint32_t first_of_digit[KPT];
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            // 16-bit counter of (digit d, this thread): word [d&7][tid], half d>>3; x4 = d << 2
+            const uint32_t l3 = __builtin_amdgcn_ubfe(x4[i], 2u, 3u);
+            const uint32_t h = x4[i] >> 5;
+            first_of_digit[i] = *reinterpret_cast<const u16_alias*>(cbytes + (l3 * CNT_ROW_BYTES + tid * 4u) + h * 2u);
+        }
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            slot[i] += first_of_digit[i];
+        }
+    };
+
+    // ---- round 0: by the low nibble, keys in registers ----------------------------------------------------------
+    uint32_t s0[KPT];
+    {
+        uint32_t x4[KPT];
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            x4[i] = __builtin_amdgcn_ubfe(field_word(k[i], hi), sh, 4u) << 2;
+        }
+        rank_round(x4, s0);
+        // the key's high nibble (<< 2) goes to whoever owns slot s0
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            lds_store_at<unsigned char>(H_BYTES + s0[i], static_cast<unsigned char>(__builtin_amdgcn_ubfe(field_word(k[i], hi), sh + 4u, 4u) << 2));
+        }
+    }
+    __syncthreads();
+    // ---- round 1: slots 16t .. 16t+15 of that order, by the high nibble -----------------------------------------
+    {
+        const U32x4 hrow = *reinterpret_cast<const U32x4*>(smem + L::H_AT + tid * 4);
+        uint32_t x4[KPT], s1[KPT];
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            x4[j] = __builtin_amdgcn_ubfe(hrow.v[j >> 2], 8u * (j & 3), 8u);
+        }
+        rank_round(x4, s1);
+        U32x4 ma, mb;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            ma.v[q] = s1[2 * q] | (s1[2 * q + 1] << 16);
+            mb.v[q] = s1[8 + 2 * q] | (s1[8 + 2 * q + 1] << 16);
+        }
+        *reinterpret_cast<U32x4*>(smem + L::M_AT + tid * 8) = ma;
+        *reinterpret_cast<U32x4*>(smem + L::M_AT + tid * 8 + 4) = mb;
+    }
+    __syncthreads();
+    // ---- final slot of this thread's own keys; one trip through the image ----------------------------------------
+    uint32_t f[KPT];
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        f[i] = *reinterpret_cast<const u16_alias*>(reinterpret_cast<const unsigned char*>(smem) + M_BYTES + s0[i] * 2u);
+    }
+    __syncthreads();                 // the image overlays the work area: nobody may still be reading M
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        lds_store_at<Key>(add_lshl<(sizeof(Key) == 4 ? 2 : 3)>(f[i], f[i] >> L::PADSH), k[i]);
+    }
+    if constexpr (PAYLOAD) {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            lds_store_at<uint32_t>(PBUF_BYTES + add_lshl<2>(f[i], f[i] >> 5), pl[i]);
+        }
+    }
+    __syncthreads();
+    // leave as runs: slot i = r*THREADS + tid, its global slot = gb[digit] + i
+    constexpr uint32_t RSTRIDE = THREADS + (THREADS >> L::PADSH);
+    const uint32_t rd_base = tid + (tid >> L::PADSH);
+    const Key* xk = reinterpret_cast<const Key*>(smem);
+    Key okey[KPT];
+#pragma unroll
+    for (int r = 0; r < KPT; ++r) {
+        okey[r] = xk[rd_base + static_cast<uint32_t>(r) * RSTRIDE];
+    }
+    uint32_t pay[PAYLOAD ? KPT : 1];
+    if constexpr (PAYLOAD) {
+        constexpr uint32_t PSTRIDE = THREADS + (THREADS >> 5);
+        const uint32_t pd_base = L::XBUF_DW + tid + (tid >> 5);
+#pragma unroll
+        for (int r = 0; r < KPT; ++r) {
+            pay[r] = smem[pd_base + static_cast<uint32_t>(r) * PSTRIDE];
+        }
+    }
+    uint32_t g[KPT];
+#pragma unroll
+    for (int r = 0; r < KPT; ++r) {
+        g[r] = gb[__builtin_amdgcn_ubfe(field_word(okey[r], hi), sh, 8u)];
+    }
+#pragma unroll
+    for (int r = 0; r < KPT; ++r) {
+        g[r] += tid + static_cast<uint32_t>(r) * THREADS;
+    }
+    if (full) {
+#pragma unroll
+        for (int r = 0; r < KPT; ++r) {
+            out[g[r]] = static_cast<Key>(okey[r] ^ flip);
+        }
+        if constexpr (PAYLOAD) {
+#pragma unroll
+            for (int r = 0; r < KPT; ++r) {
+                pout[g[r]] = pay[r];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < KPT; ++r) {
+            if (static_cast<uint32_t>(r) * THREADS + tid < valid) {
+                out[g[r]] = static_cast<Key>(okey[r] ^ flip);
+                if constexpr (PAYLOAD) {
+                    pout[g[r]] = pay[r];
+                }
+            }
+        }
     }
 }
 

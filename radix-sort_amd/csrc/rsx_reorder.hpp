@@ -44,6 +44,9 @@ constexpr uint32_t kLaDummy = 2 * kRadix * kRadix;   // one spare counter past t
 #ifndef RSX_EARLY_RANK
 #define RSX_EARLY_RANK 1
 #endif
+#ifndef RSX_SCAN_TRAILING_BARRIER
+#define RSX_SCAN_TRAILING_BARRIER 0      // round 3: the raking scan's block scan ends without its own barrier (one barrier fewer per tile)
+#endif
 #ifndef RSX_LA_REPLICAS
 #define RSX_LA_REPLICAS 2
 #endif
@@ -177,6 +180,15 @@ struct SelfScanArgs {
     uint32_t* table_out;         // last pass: leave the tile's 16 first slots in table[digit][tile] as the scan would
 };
 
+// Peer-store exchange of the sharded sort (RANGED launches only, `keys != nullptr`): bucket b does not go to `out` but to the
+// buffer keys[b] (payload: pays[b]) — device arrays of 16 addresses, each naming where THIS rank's keys of bucket b begin in the
+// receive buffer of the rank that owns the bucket (peer-mapped memory of another GPU over xGMI, or plain local memory).  A key's
+// index inside its bucket is its global slot minus the bucket's first slot, table[b][0].
+struct PeerArgs {
+    const unsigned long long* keys;      // nullptr: everything goes to `out` / `pout`
+    const unsigned long long* pays;
+};
+
 // LOOKAHEAD: while a key leaves for its slot g, the kernel also counts the key's NEXT
 // digit for the output tile g / TILE — i.e. it builds the next pass's per-tile histogram
 // (layout [tile][digit] in `next_counts`, zeroed by the host) without another pass over
@@ -194,7 +206,7 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
                                                            uint32_t tiles_per_xcd, int remap, int shift, Key flip, uint32_t mask,
                                                            uint32_t* __restrict__ next_counts, int next_shift,
                                                            const uint32_t* __restrict__ globsum, Key lo, Key mul,
-                                                           SplitSet<Key> split, SelfScanArgs self)
+                                                           SplitSet<Key> split, SelfScanArgs self, PeerArgs peer = PeerArgs{nullptr, nullptr})
 {
     using L = ReorderLayout<Key, THREADS, KPT, (!RANGED && RSX_ALIAS_COUNTERS != 0)>;
     static_assert(!(RANGED && LOOKAHEAD), "the ranged bucket function is for the one-pass partition only");
@@ -220,6 +232,19 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
     }
     if (!lds_base_is_zero(smem)) {
         __builtin_trap();           // lds_store_at addresses the staging image from LDS address 0
+    }
+    // peer-store launches: the 16 destination addresses (self-scan scratch, unused in RANGED launches; read after several barriers)
+    const bool to_peers = RANGED && peer.keys != nullptr;                 // wave-uniform
+    unsigned long long* peer_k = reinterpret_cast<unsigned long long*>(self_part);
+    unsigned long long* peer_p = peer_k + kRadix;
+    static_assert(((THREADS / kWave) * 2 * kRadix + kRadix) * 4 >= 2 * kRadix * 8, "the peer address tables fit the self-scan scratch");
+    if constexpr (RANGED) {
+        if (to_peers && tid < static_cast<uint32_t>(kRadix)) {
+            peer_k[tid] = peer.keys[tid];
+            if constexpr (PAYLOAD) {
+                peer_p[tid] = peer.pays[tid];
+            }
+        }
     }
     // bit 1 of `remap`: walk the tiles from the back (experiment: start with what the previous pass wrote last)
     const uint32_t tile = (remap & 2) ? ntiles - 1 - slot_tile : slot_tile;
@@ -283,6 +308,13 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
         const uint64_t e_hi = static_cast<uint64_t>(hl + 8) * ntiles + tile;
         first_lo = table[e_lo];
         first_hi = table[e_hi];
+        if constexpr (RANGED) {
+            if (to_peers) {
+                // index inside the bucket instead of the global slot (table[b][0] = the bucket's first slot)
+                first_lo -= table[static_cast<uint64_t>(hl) * ntiles];
+                first_hi -= table[static_cast<uint64_t>(hl + 8) * ntiles];
+            }
+        }
         if (globsum) {
             // PasteHistogram folded in: the table holds block-local prefixes, add the scanned
             // sum of the scan group (256 tiles of one digit) each entry lives in (RadixSort.cl:185-197)
@@ -496,7 +528,8 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
         U32x4 b = *reinterpret_cast<const U32x4*>(cnt + tid * 8 + 4);
         const uint32_t sum = a.v[0] + a.v[1] + a.v[2] + a.v[3] + b.v[0] + b.v[1] + b.v[2] + b.v[3];
         uint32_t total;
-        uint32_t run = block_exclusive_scan<THREADS>(sum, wtot, total);
+        // (no trailing barrier: `wtot` is not written again in this kernel, and the barrier after the packed words below orders the rest)
+        uint32_t run = block_exclusive_scan<THREADS, (RSX_SCAN_TRAILING_BARRIER != 0)>(sum, wtot, total);
         // low halves now prefix digits 0..7, high halves digits 8..15; the latter start
         // after ALL keys with digit < 8, i.e. after total.low
         run += total << 16;
@@ -567,6 +600,7 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
     Key okey[KPT];
     uint32_t g[KPT];
     uint32_t la_idx[LOOKAHEAD ? KPT : 1];
+    uint32_t bucket_of[RANGED ? KPT : 1];
 #pragma unroll
     for (int r = 0; r < KPT; ++r) {
         okey[r] = xk[rd_base + static_cast<uint32_t>(r) * RSTRIDE];
@@ -576,7 +610,8 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
 #pragma unroll
         for (int r = 0; r < KPT; ++r) {
             if constexpr (RANGED) {
-                rb[r] = runs[reinterpret_cast<const unsigned char*>(cnt)[static_cast<uint32_t>(r) * THREADS + tid]];
+                bucket_of[r] = reinterpret_cast<const unsigned char*>(cnt)[static_cast<uint32_t>(r) * THREADS + tid];
+                rb[r] = runs[bucket_of[r]];
             } else {
                 rb[r] = runs[dig(okey[r])];
             }
@@ -593,7 +628,16 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
     RSX_STAMP(6);
     // keys leave first, then the look-ahead counts: both free their registers before the
     // payload takes its own trip through the staging image
-    if (full) {
+    if (RANGED && to_peers) {
+        if constexpr (RANGED) {
+#pragma unroll
+            for (int r = 0; r < KPT; ++r) {
+                if (full || static_cast<uint32_t>(r) * THREADS + tid < valid) {
+                    reinterpret_cast<Key*>(peer_k[bucket_of[r]])[g[r]] = okey[r];
+                }
+            }
+        }
+    } else if (full) {
 #pragma unroll
         for (int r = 0; r < KPT; ++r) {
             out[g[r]] = okey[r];
@@ -648,6 +692,12 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
         for (int r = 0; r < KPT; ++r) {
             const uint32_t i = static_cast<uint32_t>(r) * THREADS + tid;
             if (full || i < valid) {
+                if constexpr (RANGED) {
+                    if (to_peers) {
+                        reinterpret_cast<uint32_t*>(peer_p[bucket_of[r]])[g[r]] = pay[r];
+                        continue;
+                    }
+                }
                 pout[g[r]] = pay[r];
             }
         }

@@ -218,7 +218,10 @@ __global__ __launch_bounds__(kScanTiles) void paste_scan_kernel(uint32_t* __rest
 // the table's second read and write, and the 32 wave scans of the paste.  `epoch` is the engine's launch
 // count (never 0).  A poll that runs out sets *timeout and lets the workgroup finish with garbage rather
 // than hang the GPU (rsx_sync / rsx_download report it).
-constexpr int kFusedScanMaxGroups = 512;      // 2^29 keys; 256-thread workgroups, <= 2 per CU: all resident with room to spare (its registers allow 4)
+// kFusedScanMaxGroups sizes the granule buffer only.  Which tables actually take this kernel is decided per engine from the
+// occupancy query (workgroups resident at once = per-CU answer x CU count; half of that is the limit, rsx_create): on a whole
+// MI355X that is the full 512 groups (2^29 keys), on a partitioned device or under a CU mask correspondingly fewer.
+constexpr int kFusedScanMaxGroups = 512;
 typedef __attribute__((address_space(1))) uint32_t gu32;
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(kScanTiles) void scan_fused_kernel(uint32_t* __rest
                 while (static_cast<uint32_t>(x[b] >> 32) != epoch) {
                     __builtin_amdgcn_s_sleep(1);
                     if (++spins > (1u << 22)) {              // seconds: something is badly wrong; do not hang the device
-                        __hip_atomic_store((gu32*)(timeout), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store((gu32*)(timeout), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // mapped host memory
                         break;
                     }
                     x[b] = __hip_atomic_load((gu64*)(sums) + static_cast<uint64_t>(g2) * kRadix + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -363,6 +366,14 @@ __global__ __launch_bounds__(kScanTiles) void scan_fused_kernel(uint32_t* __rest
         for (int d = 0; d < kRadix; ++d) {
             table[static_cast<uint64_t>(d) * ntiles + tile] = ex[d] + off[d];
         }
+    }
+}
+
+// tests only (RSX_OPT_DEBUG_RAISE_SCAN_TIMEOUT): the store a timed-out sweep makes, without the sweep
+__global__ void raise_flag_kernel(uint32_t* flag)
+{
+    if (threadIdx.x == 0) {
+        __hip_atomic_store((gu32*)(flag), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

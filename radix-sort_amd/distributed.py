@@ -15,6 +15,13 @@ across shards, but a most-significant-bits partition is, so the data path is:
   pass fewer (`rsx_sort_from_to`) straight into its place in the output.  All but the first wave of
   the exchange hides behind the local sorts, and partition + 7 passes is the single-GPU pass count.
 
+  1b. Peer-store variant of 1 (strategy="waves-p2p", selectable; RCCL stays the default until a scaling curve exists): the
+  receive buffers are peer-visible device memory (`rsx_peer_alloc`, mapped by the other ranks once through IPC handles), and the
+  wave-major scatter writes every bucket STRAIGHT to its place in the owner's receive buffer (`rsx_partition_scatter_waves_peer`;
+  the places follow from the gathered count table, `wave_layout`).  No staging write, no re-read, no all-to-all launch: the
+  exchange is the scatter kernel's stores over xGMI, closed by one tiny all_reduce on the stream (every rank's scatter has
+  finished before anybody sorts what it received).
+
   2. Plain top-bit path (other world sizes, no output buffer, or strategy="top"): the same 16 buckets
   in key order (`rsx_partition_count` / `rsx_partition_scatter`), dealt to the ranks as contiguous
   ranges balanced on the global counts, ONE all-to-all, full local sort.  Also taken when dealing the
@@ -193,6 +200,31 @@ def plan_exchange(bucket_offsets: list[int], rank: int, world_size: int, dist, d
     return plan, all_caps
 
 
+def wave_layout(table: list[list[int]], world_size: int) -> tuple[list[list[int]], list[list[list[int]]], list[int]]:
+    """Where everything lands in the receive buffers of the pipelined paths, from the gathered [source][wave * world + dest]
+    count table: at destination d the waves follow each other, each starting on a 16-byte boundary (4 keys: the local sort
+    loads 16 bytes per lane), and inside a wave the sources follow each other in rank order.  Returns
+    (start[d][w] — first slot of wave w at destination d, offset[d][w][s] — first slot of source s's keys in it,
+    load[d] — keys destination d ends up with)."""
+    k = RADIX // world_size
+    start, offset, load = [], [], []
+    for d in range(world_size):
+        at, st, of, total = 0, [], [], 0
+        for w in range(k):
+            at = (at + 3) & ~3
+            st.append(at)
+            row = []
+            for src in range(world_size):
+                row.append(at)
+                at += table[src][w * world_size + d]
+                total += table[src][w * world_size + d]
+            of.append(row)
+        start.append(st)
+        offset.append(of)
+        load.append(total)
+    return start, offset, load
+
+
 SAMPLES_PER_RANK = 1024
 MAX_SPLITTERS = 7           # 2*7+1 = 15 buckets fit the 16-bucket kernels
 
@@ -303,7 +335,7 @@ class ShardedSorter:
         self.max_imbalance = 1.25      # top-bit buckets are used when no rank would get more than this x its share
         # general path when the top bits do not balance: "split" (sampled splitters, <= 8 ranks),
         # "range" (equal-width buckets over the global key range), "auto" = split where possible
-        if strategy not in ("auto", "waves", "split", "range", "top"):
+        if strategy not in ("auto", "waves", "waves-p2p", "split", "range", "top"):
             raise ValueError(f"unknown strategy {strategy!r}")
         if strategy == "split" and world_size > MAX_SPLITTERS + 1:
             raise ValueError(f"the splitter path serves at most {MAX_SPLITTERS + 1} ranks")
@@ -315,6 +347,54 @@ class ShardedSorter:
         self.record_timeline = False
         self._marks = []
         self._count_row = self._count_table = self._count_row_caps = None      # device row of the pipelined path's counts (+ capacities)
+        self._peer = None              # peer-store exchange: receive buffers of every rank as this rank addresses them (setup_peer_exchange)
+
+    # -- peer-store exchange ------------------------------------------------------------------------------------------------
+    def setup_peer_exchange(self, capacity: int, device, with_payload: bool = False) -> None:
+        """Collective, once: every rank allocates a peer-visible receive buffer of `capacity` keys (and payloads) and learns
+        how to address everybody else's — the pointer itself for ranks that are threads of this process, an opened IPC handle
+        (lazy peer access over xGMI) for ranks in other processes.  Needed by strategy "waves-p2p"."""
+        import os
+        import numpy as np
+        import torch
+        if self._peer is not None:
+            self.close_peer_exchange()
+        itemsize = self.key_bits // 8
+        kaddr, khandle = self.engine.peer_alloc(capacity * itemsize)
+        paddr, phandle = self.engine.peer_alloc(capacity * 4) if with_payload else (0, bytes(64))
+        row = [os.getpid(), kaddr, paddr] + [int(v) for v in np.frombuffer(khandle, dtype=np.int64)] + [int(v) for v in np.frombuffer(phandle, dtype=np.int64)]
+        rows = [row]
+        if self.dist is not None:
+            t = torch.tensor(row, dtype=torch.int64, device=device)
+            gathered = torch.empty(self.world * len(row), dtype=torch.int64, device=device)
+            self.dist.all_gather_into_tensor(gathered, t)
+            rows = gathered.cpu().view(self.world, len(row)).tolist()
+        keys, pays, opened = [], [], []
+        for r, other in enumerate(rows):
+            if r == self.rank or other[0] == os.getpid():
+                keys.append(other[1])
+                pays.append(other[2])
+            else:
+                keys.append(self.engine.peer_open(np.array(other[3:11], dtype=np.int64).tobytes()))
+                opened.append(keys[-1])
+                if with_payload:
+                    pays.append(self.engine.peer_open(np.array(other[11:19], dtype=np.int64).tobytes()))
+                    opened.append(pays[-1])
+                else:
+                    pays.append(0)
+        self._peer = {"capacity": capacity, "keys": keys, "pays": pays, "opened": opened, "mine": (kaddr, paddr), "payload": with_payload,
+                      "fence": torch.zeros(1, dtype=torch.int32, device=device)}
+
+    def close_peer_exchange(self) -> None:
+        """Unmaps the other ranks' buffers and frees this rank's (collective in effect: nobody may still be writing)."""
+        if self._peer is None:
+            return
+        for p in self._peer["opened"]:
+            self.engine.peer_close(p)
+        for p in self._peer["mine"]:
+            if p:
+                self.engine.peer_free(p)
+        self._peer = None
 
     def _mark(self, label):
         if self.record_timeline:
@@ -355,7 +435,20 @@ class ShardedSorter:
         self.result_in_out = False
         self._marks = []
         self._bind_stream(keys)
-        self._caps = (recv.numel() if recv is not None else 0, out.numel() if out is not None else 0)
+        # what this rank can receive / hold at the end, in keys: with a payload the smaller of the key and the payload buffer
+        # (a short payload buffer would otherwise fail in the all-to-all on ONE rank and leave the others hanging)
+        def cap(a, b):
+            if a is None or (payload is not None and b is None):
+                return 0
+            return a.numel() if payload is None else min(a.numel(), b.numel())
+        self._caps = (cap(recv, recv_payload), cap(out, out_payload))
+        if self.strategy == "waves-p2p" and self._peer is not None:
+            self._caps = (self._peer["capacity"], self._caps[1])      # what this rank receives into is its peer-visible buffer
+        # a fused table scan of an EARLIER step that timed out is reported here (no synchronisation; see rsx_check_status) —
+        # callers end a batch of steps with engine.sync(), which reports the last one's
+        check = getattr(self.engine, "check_status", None)
+        if check is not None:
+            check()
         self._mark("start")
         if self.world == 1 and not self.force_exchange:
             self.engine.sort_from(keys.data_ptr(), n, payload.data_ptr() if payload is not None else None)
@@ -367,6 +460,10 @@ class ShardedSorter:
         if self.strategy == "waves" and not can_pipeline:
             raise ValueError("strategy 'waves' needs an output buffer and 1, 2, 4, 8 or 16 ranks")
         self._plain_table = None
+        if self.strategy == "waves-p2p":
+            if not can_pipeline or self._peer is None or (payload is not None and not self._peer["payload"]):
+                raise ValueError("strategy 'waves-p2p' needs an output buffer, 1, 2, 4, 8 or 16 ranks and setup_peer_exchange() (with a payload buffer if a payload is carried)")
+            return self._sort_in_waves_p2p(keys, n, payload, out, out_payload, pay_in)
         if self.strategy == "waves" or (self.strategy == "auto" and can_pipeline):
             done = self._sort_in_waves(keys, n, staging, recv, payload, staging_payload, recv_payload, out, out_payload, pay_in, pay_st)
             if done is not None:
@@ -469,6 +566,44 @@ class ShardedSorter:
         self.last_path, self.last_imbalance, self.result_in_out = "waves", imbalance, True
         return done
 
+    def _sort_in_waves_p2p(self, keys, n, payload, out, out_payload, pay_in):
+        """Pipelined path with the exchange done by the scatter kernel's own stores into the owners' receive buffers."""
+        world, k = self.world, RADIX // self.world
+        itemsize = self.key_bits // 8
+        if self.dist is not None and getattr(keys, "is_cuda", False) and hasattr(self.engine, "partition_count_waves_device"):
+            table, caps = self._gather_wave_counts_on_device(keys, n)
+        else:
+            counts = self.engine.partition_count_waves(keys.data_ptr(), n, world)
+            table, caps = gather_counts(counts, world, self.dist, keys.device, self._caps)
+        # (the all_gather above is also the step's opening barrier: it completes only once every rank has enqueued its own, behind
+        # the local sorts of its previous step — nobody is still reading the receive buffer this step is about to write into)
+        start, offset, loads = wave_layout(table, world)
+        self.last_imbalance = max(loads) / max(1.0, sum(loads) / world)
+        self._mark("count+plan")
+        check_capacity(loads, caps, need_out=True, slack=4 * k)          # every rank alike: gathered data only
+        peer_keys = [self._peer["keys"][p % world] + offset[p % world][p // world][self.rank] * itemsize for p in range(RADIX)]
+        peer_pays = [self._peer["pays"][p % world] + offset[p % world][p // world][self.rank] * 4 for p in range(RADIX)] if payload is not None else None
+        self.engine.partition_scatter_waves_peer(keys.data_ptr(), n, peer_keys, pay_in, peer_pays)
+        self._mark("scatter")
+        if self.dist is not None:
+            self.dist.all_reduce(self._peer["fence"])                    # every rank's scatter has finished: what this rank received is complete
+        self._mark("fence")
+        passes = self.key_bits // PARTITION_BITS - 1
+        mine_k, mine_p = self._peer["mine"]
+        done = 0
+        for w in range(k):
+            n_recv = sum(table[src][w * world + self.rank] for src in range(world))
+            if n_recv:
+                at = start[self.rank][w]
+                self.engine.sort_from_to(
+                    mine_k + at * itemsize, n_recv, 0, passes, out[done:].data_ptr(),
+                    mine_p + at * 4 if payload is not None else None,
+                    out_payload[done:].data_ptr() if payload is not None else None)
+            done += n_recv
+        self._mark("local_sort")
+        self.last_path, self.result_in_out = "waves-p2p", True
+        return done
+
     def _gather_wave_counts_on_device(self, keys, n):
         """gather_counts for the pipelined path without the host in the middle: the engine leaves its 16 counts in a device
         row that also carries this rank's two buffer capacities, the row goes into the all_gather as it is, and only the
@@ -508,7 +643,9 @@ class ShardedSorter:
         return self._exchange_and_sort(plan, n, staging, recv, payload, staging_payload, recv_payload)
 
     def _exchange_and_sort(self, plan, n, staging, recv, payload, staging_payload, recv_payload):
-        assert plan.n_recv <= recv.numel()      # check_capacity ran on every rank before anything moved
+        if plan.n_recv > recv.numel() or (payload is not None and plan.n_recv > recv_payload.numel()):
+            # unreachable after check_capacity (which ran on every rank, on gathered data, before anything moved): a bug, not an input
+            raise RuntimeError(f"rank {self.rank}: the exchange plan delivers {plan.n_recv} keys into a receive buffer of {recv.numel()}")
         self.dist.all_to_all_single(recv[:plan.n_recv], staging[:n], plan.recv, plan.send)
         if payload is not None:
             self.dist.all_to_all_single(recv_payload[:plan.n_recv], staging_payload[:n], plan.recv, plan.send)

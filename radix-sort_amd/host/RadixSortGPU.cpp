@@ -1,3 +1,4 @@
+#include <algorithm>
 #include "RadixSortGPU.h"
 
 #include "Common/CTimer.h"
@@ -143,9 +144,16 @@ void RadixSortGPU<DataType>::CopyDataFromDevice(hipc::CommandQueue)
     // table (_RADIX*_NUM_ITEMS words, [digit][group][item]) and the scanned block sums
     // (_NUM_HISTOSPLIT words) — src/RadixSortGPU.cpp:390-429.  The engine recomputes both in the
     // reference's geometry (RSX_OPT_REF_DIAGNOSTICS); nothing consumes them, they are for parity.
+    // With 8-bit digits (setRadixBits(8)) no pass of the sort is the reference's last 4-bit pass, so its two tables do not exist:
+    // they are not asked for (the engine refuses to hand out tables the last sort did not produce) and are left zeroed.
+    const bool tables = mRadixBits == 4;
+    if (!tables) {
+        std::fill(mHostSpans.m_hHistograms.begin(), mHostSpans.m_hHistograms.end(), 0u);
+        std::fill(mHostSpans.m_hGlobsum.begin(), mHostSpans.m_hGlobsum.end(), 0u);
+    }
     mLastStatus = rsx_download(mEngine, mHostSpans.m_hResultFromGPU.data(), mWithPermutation ? mHostSpans.h_Permut.data() : nullptr,
-                               mHostSpans.m_hHistograms.data(), mHostSpans.m_hHistograms.data() ? Parameters::_RADIX * Parameters::_NUM_ITEMS : 0,
-                               mHostSpans.m_hGlobsum.data(), mHostSpans.m_hGlobsum.data() ? Parameters::_NUM_HISTOSPLIT : 0);
+                               mHostSpans.m_hHistograms.data(), (tables && mHostSpans.m_hHistograms.data()) ? Parameters::_RADIX * Parameters::_NUM_ITEMS : 0,
+                               mHostSpans.m_hGlobsum.data(), (tables && mHostSpans.m_hGlobsum.data()) ? Parameters::_NUM_HISTOSPLIT : 0);
 }
 
 template <typename DataType>

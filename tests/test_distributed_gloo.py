@@ -331,7 +331,7 @@ def test_choose_splitters_and_split_plan():
         assert cuts == sorted(cuts) and [p.n_recv for p in plans] == [cuts[i + 1] - cuts[i] for i in range(world)]
 
 
-def _overflow_worker(rank, world, port, strategy, q):
+def _overflow_worker(rank, world, port, strategy, q, short_payload=False):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -344,12 +344,20 @@ def _overflow_worker(rank, world, port, strategy, q):
         full = Oracle().dataset("SeededUniform", "uint32", n * world, seed=3)
         keys = torch.from_numpy(full[rank * n:(rank + 1) * n].copy().view(np.int32))
         staging = torch.empty_like(keys)
-        # rank 1's receive buffer is far too small; rank 0's is generous
-        recv = torch.empty(n * world if rank == 0 else n // 4, dtype=keys.dtype)
+        # rank 1's receive buffer is far too small; rank 0's is generous.  short_payload: the KEY buffers are generous everywhere
+        # and only rank 1's payload receive buffer is short — the capacity that travels in the all_gather is the smaller of the two
+        small = rank == 1
+        recv = torch.empty(n // 4 if (small and not short_payload) else n * world, dtype=keys.dtype)
         out = torch.empty(n * world, dtype=keys.dtype)
+        pay = spay = rpay = opay = None
+        if short_payload:
+            pay = torch.arange(n, dtype=torch.int32)
+            spay = torch.empty_like(pay)
+            rpay = torch.empty(n // 4 if small else n * world, dtype=torch.int32)
+            opay = torch.empty(n * world, dtype=torch.int32)
         sorter = d.ShardedSorter(_CpuEngineDouble("uint32"), rank, world, 32, dist, strategy=strategy)
         try:
-            sorter.sort(keys, staging, recv, None, None, None, out, None)
+            sorter.sort(keys, staging, recv, pay, spay, rpay, out, opay)
             q.put((rank, "no error"))
         except d.CapacityError as exc:
             q.put((rank, "capacity:" + str(exc)))
@@ -358,15 +366,16 @@ def _overflow_worker(rank, world, port, strategy, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("strategy", ["auto", "waves", "top", "split", "range"])
-def test_too_small_receive_buffer_raises_on_every_rank(strategy):
-    """One rank's receive buffer cannot hold its share: EVERY rank must raise before any all_to_all
-    is issued (a lone raise would leave the peers hanging in the collective)."""
+@pytest.mark.parametrize("strategy,short_payload", [("auto", False), ("waves", False), ("top", False), ("split", False), ("range", False),
+                                                    ("auto", True), ("top", True), ("split", True)])
+def test_too_small_receive_buffer_raises_on_every_rank(strategy, short_payload):
+    """One rank's receive buffer (or, with a payload, only its PAYLOAD receive buffer) cannot hold its share: EVERY rank
+    must raise before any all_to_all is issued (a lone raise would leave the peers hanging in the collective)."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_overflow_worker, args=(r, 2, port, strategy, q)) for r in range(2)]
+    procs = [ctx.Process(target=_overflow_worker, args=(r, 2, port, strategy, q, short_payload)) for r in range(2)]
     for p in procs:
         p.start()
     outs = sorted(q.get(timeout=120) for _ in range(2))

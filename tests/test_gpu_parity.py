@@ -531,7 +531,13 @@ def test_fused_scan_equals_the_separate_launches(mod, oracle, dt, payload, n):
             for _ in range(3):                    # epochs advance; granules of earlier launches must never be taken for current ones
                 e.sort()
             g = e.geometry()
-            out = e.download(want_perm=payload, hist_cap=int(g.table_len), globsum_cap=int(g.num_scan_blocks))
+            # (the one-workgroup scan of small tables leaves no group sums: asking for them is an error, checked below)
+            has_sums = not (small and g.num_tiles <= 1024)
+            out = e.download(want_perm=payload, hist_cap=int(g.table_len), globsum_cap=int(g.num_scan_blocks) if has_sums else 0)
+            if not has_sums:
+                with pytest.raises(mod.RadixSortError):
+                    e.download(globsum_cap=int(g.num_scan_blocks))
+                out = out + (None,)
             seen.append(out if isinstance(out, tuple) else (out,))
     want = np.sort(keys)
     for got in seen:
@@ -916,3 +922,151 @@ def test_graph_replay_small_sorts(mod, oracle):
             e.sort_from(ta.data_ptr(), n, tp.data_ptr())
             torch.cuda.synchronize()
             assert np.array_equal(e.download(), np.sort(b))
+
+
+def test_fused_scan_group_limit_comes_from_the_occupancy_query(mod, oracle):
+    """The fused table scan's workgroups wait for each other inside one launch, so only tables the device holds at once may
+    take it: the limit is derived from hipOccupancyMaxActiveBlocksPerMultiprocessor x CU count at rsx_create (half of it),
+    RSX_OPT_FUSED_SCAN_MAX_GROUPS moves it (clamped to what is resident), and a table beyond it takes the two-launch scan
+    — same keys, same table, same group sums; the time-out word stays clear."""
+    n = (1 << 24) + 4097                    # 4098 tiles = 17 scan groups: beyond the self-scan, inside the default limit
+    keys = oracle.dataset("SeededUniform", "uint32", n, seed=3)
+    want = np.sort(keys)
+    seen = []
+    for limit in (-1, 4, 0, 1 << 20):
+        with mod.Engine("uint32", n) as e:
+            g = e.geometry()
+            assert g.fused_scan_resident >= 256 and 0 < g.fused_scan_max_groups <= min(512, g.fused_scan_resident // 2)
+            e.set_option(mod.OPT_FUSED_SCAN_MAX_GROUPS, limit)
+            now = e.geometry().fused_scan_max_groups
+            assert now == {-1: g.fused_scan_max_groups, 4: 4, 0: 0, 1 << 20: min(512, g.fused_scan_resident)}[limit]
+            e.set_option(mod.OPT_PROFILE, 1)
+            e.upload(keys)
+            for _ in range(2):
+                e.sort()
+            e.sync()                                                       # reports a timed-out scan: must not
+            rt = e.timings()
+            # fused: one scan launch per pass; beyond the limit: scan #1 (timeScan) + scan #2/paste (timePaste)
+            fused = 17 <= now
+            assert (rt.paste.n == 0) == fused, (limit, now, rt.scan.n, rt.paste.n)
+            g = e.geometry()
+            seen.append(e.download(hist_cap=int(g.table_len), globsum_cap=int(g.num_scan_blocks)))
+    for got in seen:
+        assert np.array_equal(got[0], want)
+        for a, b in zip(seen[0], got):
+            assert np.array_equal(a, b)
+    with mod.Engine("uint32", 4096) as e:
+        with pytest.raises(mod.RadixSortError):
+            e.set_option(mod.OPT_FUSED_SCAN_MAX_GROUPS, -2)
+
+
+def test_two_engines_run_fused_scans_at_the_same_time(mod, oracle):
+    """Two engines of >= 2^24 keys on two streams, both through the fused scan (each may use half of what the device holds
+    at once): results exact, the time-out word clear on both."""
+    import torch
+    na, nb = (1 << 24) + 12345, (1 << 25) + 1
+    a = oracle.dataset("SeededUniform", "uint32", na, seed=21)
+    b = oracle.dataset("SeededUniform", "uint64", nb, seed=22)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    ta = torch.from_numpy(a.view(np.int32)).cuda()
+    tb = torch.from_numpy(b.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    with mod.Engine("uint32", na) as e1, mod.Engine("uint64", nb) as e2:
+        assert e1.geometry().fused_scan_max_groups >= 17 and e2.geometry().fused_scan_max_groups >= 33
+        e1.set_stream(s1.cuda_stream)
+        e2.set_stream(s2.cuda_stream)
+        for _ in range(4):
+            e1.sort_from(ta.data_ptr(), na)
+            e2.sort_from(tb.data_ptr(), nb)
+        e1.sync()
+        e2.sync()
+        e1.check_status()
+        e2.check_status()
+        assert np.array_equal(e1.download(), np.sort(a))
+        assert np.array_equal(e2.download(), np.sort(b))
+
+
+def test_scan_timeout_is_reported_once_and_the_engine_stays_usable(mod, oracle):
+    """The word a timed-out fused scan stores to (mapped host memory) is reported by the next synchronising call — and by
+    rsx_copy_result / rsx_check_status for work that has finished — exactly once; afterwards the engine sorts again."""
+    import torch
+    n = 100000
+    keys = oracle.dataset("SeededUniform", "uint32", n, seed=4)
+    dst = torch.empty(n, dtype=torch.int32, device="cuda")
+    with mod.Engine("uint32", n) as e:
+        e.upload(keys)
+        e.sort()
+        e.sync()
+        for report in ("sync", "download", "copy_result", "check_status"):
+            e.set_option(mod.OPT_DEBUG_RAISE_SCAN_TIMEOUT, 1)          # the store a starved workgroup makes, on the engine's stream
+            torch.cuda.synchronize()
+            with pytest.raises(mod.RadixSortError) as err:
+                {"sync": e.sync, "download": e.download, "copy_result": lambda: e.copy_result(dst.data_ptr()), "check_status": e.check_status}[report]()
+            assert "timed out" in str(err.value)
+            e.sync()                                                       # cleared: reported once
+            e.check_status()
+            e.upload(keys)
+            e.sort()
+            assert np.array_equal(e.download(), np.sort(keys))
+
+
+def test_download_refuses_tables_the_last_sort_did_not_produce(mod, oracle):
+    """rsx_download hands out the engine's own [digit][tile] table / group sums only when the last sort produced them: sorts on
+    1024-key tiles and 8-bit passes leave none (an earlier sort's would be silently stale); the reference-geometry
+    diagnostics work on every path."""
+    n = 1 << 16
+    keys = oracle.dataset("Random", "uint32", n)
+    with mod.Engine("uint32", 1 << 21) as e:
+        e.upload(keys)
+        e.sort()                                                           # default: self-scan on tiles of 1024 keys
+        assert np.array_equal(e.download(), np.sort(keys))
+        with pytest.raises(mod.RadixSortError):
+            e.download(hist_cap=16 * 16)
+        e.set_option(mod.OPT_SMALL_TILE_MAX_KEYS, 0)                       # self-scan on 4096-key tiles: a table, no group sums
+        e.upload(keys)
+        e.sort()
+        _, table = e.download(hist_cap=16 * 16)
+        assert int(table[0]) == 0
+        with pytest.raises(mod.RadixSortError):
+            e.download(globsum_cap=16)
+        big = oracle.dataset("SeededUniform", "uint32", 1 << 21, seed=8)
+        e.set_option(mod.OPT_RADIX_BITS, 8)
+        e.upload(big)
+        e.sort()
+        assert np.array_equal(e.download(), np.sort(big))
+        with pytest.raises(mod.RadixSortError):
+            e.download(hist_cap=16)
+        e.set_option(mod.OPT_RADIX_BITS, 4)
+        e.set_option(mod.OPT_SELF_SCAN, 0)
+        e.set_option(mod.OPT_SMALL_SCAN, 0)                                # (the one-workgroup scan of small tables leaves no group sums either)
+        e.upload(big)
+        e.sort()
+        _, table, gs = e.download(hist_cap=16 * 512, globsum_cap=32)
+        assert int(table[0]) == 0 and int(gs[0]) == 0
+    want_sorted, want_table, want_gs = oracle.emulate_reference_gpu(keys)
+    with mod.Engine("uint32", n) as e:
+        e.set_option(mod.OPT_REF_DIAGNOSTICS, 1)
+        e.upload(keys)
+        e.sort()
+        got, table, gs = e.download(hist_cap=16384, globsum_cap=512)
+        assert np.array_equal(got, want_sorted) and np.array_equal(table, want_table) and np.array_equal(gs, want_gs)
+
+
+def test_graph_capture_with_8bit_digits_allocates_outside_the_capture(mod, oracle):
+    """RSX_OPT_GRAPH with 8-bit digits: the 8-bit tables are allocated before the capture begins (an allocation inside
+    hipStreamBeginCapture invalidates it), so the first call already captures and every call sorts."""
+    n = 1 << 21
+    keys = oracle.dataset("SeededUniform", "uint32", n, seed=6)
+    want = np.sort(keys)
+    for order in ("graph_first", "bits_first"):
+        with mod.Engine("uint32", n) as e:
+            if order == "graph_first":
+                e.set_option(mod.OPT_GRAPH, 1)
+                e.set_option(mod.OPT_RADIX_BITS, 8)
+            else:
+                e.set_option(mod.OPT_RADIX_BITS, 8)
+                e.set_option(mod.OPT_GRAPH, 1)
+            for _ in range(3):
+                e.upload(keys)
+                e.sort()
+                assert np.array_equal(e.download(), want)

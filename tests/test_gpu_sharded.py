@@ -80,6 +80,10 @@ class _RankDist:
         import torch
         self._collective(t, lambda parts: out.copy_(torch.cat(parts)), False)
 
+    def all_reduce(self, t, op=None):
+        # used as a stream-ordered barrier only (the peer-store exchange's closing fence): the value is not looked at
+        self._collective(t, lambda parts: None, False)
+
     def all_to_all_single(self, out, inp, out_splits, in_splits, async_op=False):
         def body(parts):
             pos = 0
@@ -443,3 +447,201 @@ def test_bench_ranks_as_processes_on_the_shared_gpu(ranks, extra, env):
     want_path = {"split": "split", "range": "range"}.get(env.get("RSX_STRATEGY"), "split" if "Zeros" in extra else "waves")
     assert f"[{want_path}]" in line["config"]["parallelism"], line["config"]["parallelism"]
     assert line["roofline"]["avg_launch_ms"] > 0
+
+
+# --------------------------------------------------------------------------- BASELINE config 4 at its real size
+def _shard(kind, dtype, offset, n, total):
+    """A rank's contiguous shard of the ONE dataset (the product's own generator, host C ABI)."""
+    import ctypes as C
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = C.CDLL(os.path.join(root, "radix-sort_amd", "host", "libradixsort_host.so"))
+    lib.rsxh_dataset_fill_shard.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]
+    lib.rsxh_dataset_fill_shard.restype = C.c_int
+    out = np.empty(n, dtype=dtype)
+    kinds = {"Zeros": 0, "Range": 1, "InvertedRange": 2, "Random": 3}
+    dts = {"uint32": 0, "int32": 1, "uint64": 2, "int64": 3}
+    assert lib.rsxh_dataset_fill_shard(kinds[kind], dts[dtype], out.ctypes.data, offset, n, total, 0) == 0
+    return out
+
+
+@pytest.mark.parametrize("radix_bits", [4, 8])
+def test_config4_2pow30_uint32_over_eight_ranks_bit_exact(rsx, radix_bits):
+    """BASELINE config 4 at its real size and decomposition: 2^30 uint32 `Random` keys as eight contiguous shards of 2^27
+    (rank r = draws r*2^27.. of the generator's stream), eight ranks with their own engine, streams and ShardedSorter — as
+    eight THREADS of this one process on the box's one GPU (the pool's process guard admits at most 6 processes on a card,
+    so eight rank processes cannot run here; four do: test_bench_config4_input_and_size_as_four_rank_processes), collectives
+    = the loopback above with RCCL's stream semantics.  Two pipelined waves per rank; the concatenation of the ranks'
+    outputs must equal a host sort of all 2^30 keys, key for key."""
+    import torch
+    from radix_sort_amd.distributed import ShardedSorter
+    world, n = 8, 1 << 27
+    total = world * n
+    hub = _Loopback(world)
+    shards, results, errors = [None] * world, [None] * world, []
+
+    def run(rank):
+        try:
+            shards[rank] = _shard("Random", "uint32", rank * n, n, total)
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                keys = torch.from_numpy(shards[rank].view(np.int32)).cuda()
+                staging = torch.empty_like(keys)
+                recv = torch.empty(2 * n, dtype=keys.dtype, device="cuda")
+                obuf = torch.empty_like(recv)
+                with rsx.Engine("uint32", 2 * n) as eng:
+                    eng.set_stream(stream.cuda_stream)
+                    if radix_bits != 4:
+                        eng.set_option(rsx.OPT_RADIX_BITS, radix_bits)
+                    sorter = ShardedSorter(eng, rank, world, 32, hub.view(rank))
+                    for _ in range(2):                       # twice: buffers, epochs and count rows are reused
+                        n_local = sorter.sort(keys, staging, recv, None, None, None, obuf, None)
+                    eng.sync()                               # reports a timed-out table scan, if any
+                    assert sorter.result_in_out and sorter.last_path == "waves"
+                    results[rank] = obuf[:n_local].cpu().numpy().view(np.uint32)
+        except Exception as exc:   # noqa: BLE001 - surface in the main thread
+            errors.append(exc)
+            hub.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=900)
+    assert not errors, errors
+    sizes = [r.size for r in results]
+    assert sum(sizes) == total and max(sizes) <= 1.25 * n
+    full = np.concatenate(shards)
+    del shards
+    assert [int(v) for v in full[:4]] == [2421477274, 811668573, 145020712, 106868501]      # the reference's Random stream (SURVEY §8c)
+    full.sort()
+    at = 0
+    for r in results:                                        # rank-order concatenation == the host sort, piece by piece
+        assert np.array_equal(r, full[at:at + r.size])
+        at += r.size
+
+
+@pytest.mark.parametrize("extra", [[], ["--radix-bits", "8"]])
+def test_bench_config4_input_and_size_as_four_rank_processes(extra):
+    """`python bench.py --gpus 4` with its default workload for N > 1 — BASELINE config 4's input and size: 2^30 uint32 keys,
+    contiguous shards of the one `Random` stream — as the driver runs it: bench.py starts the rank PROCESSES itself (four of
+    them, 2^28 keys each: the box admits at most 6 processes on its one GPU, so config 4's eight ranks run as threads in the
+    test above), every rank on cuda:0 with its own engine, gloo collectives staged through the host.  Rank 0 gathers all
+    outputs and compares them with a host sort of all 2^30 keys."""
+    line = _bench(["--gpus", "4", "--steps", "1", "--warmup", "1"] + extra, {"RSX_BENCH_SHARED_GPU": "1"})
+    assert line["n_gpus"] == 4 and line["rehearsal"] is True and line["value"] is None and line["scaling"] == "strong"
+    assert line["config"]["total_keys"] == 1 << 30 and line["config"]["keys_per_gpu"] == 1 << 28
+    assert line["config"]["verified"] == "bit-exact vs a host sort of all 1073741824 keys, gathered on rank 0"
+    assert "[waves]" in line["config"]["parallelism"] and "x4" in line["config"]["parallelism"]
+    assert "contiguous shards of one Random dataset" in line["config"]["workload"]
+    if not extra:
+        assert "BASELINE config 4's input and size over 4 ranks" in line["config"]["workload"]
+    assert {"count+plan", "scatter", "wait", "local_sort"} <= set(line["sharded_phases_ms"])
+
+
+# --------------------------------------------------------------------------- peer-store exchange
+@pytest.mark.parametrize("dt,world,with_payload", [("uint32", 8, False), ("int64", 2, True), ("uint64", 16, True), ("int32", 4, False)])
+def test_wave_scatter_straight_to_destination_addresses(rsx, oracle, dt, world, with_payload):
+    """rsx_partition_scatter_waves_peer: bucket p (wave-major position) lands at the p-th of 16 destination addresses —
+    arbitrary places at element alignment, here odd offsets of separately allocated buffers — stable, payload alongside."""
+    import torch
+    n = 200003
+    keys = oracle.dataset("SeededUniform", dt, n, seed=world)
+    signed = {"uint32": np.int32, "uint64": np.int64}.get(np.dtype(dt).name)
+    tk = torch.from_numpy(keys.view(signed) if signed else keys).cuda()
+    pay = torch.arange(n, dtype=torch.int32, device="cuda")
+    bits = keys.dtype.itemsize * 8
+    u = keys.view(np.uint32 if bits == 32 else np.uint64)
+    if keys.dtype.kind == "i":
+        u = u ^ u.dtype.type(1 << (bits - 1))
+    b = (u >> u.dtype.type(bits - 4)).astype(np.int64)
+    k = 16 // world
+    pos = (b % k) * world + b // k
+    with rsx.Engine(dt, n, payload=with_payload) as e:
+        e.set_stream(torch.cuda.current_stream().cuda_stream)
+        counts = e.partition_count_waves(tk.data_ptr(), n, world)
+        assert counts == [int(v) for v in np.bincount(pos, minlength=16)]
+        bufs = [torch.full((c + 9,), -7, dtype=tk.dtype, device="cuda") for c in counts]
+        pbufs = [torch.full((c + 9,), -7, dtype=torch.int32, device="cuda") for c in counts]
+        e.partition_scatter_waves_peer(tk.data_ptr(), n, [bufs[p][p % 5 + 1:].data_ptr() for p in range(16)], pay.data_ptr() if with_payload else None,
+                                       [pbufs[p][p % 5 + 1:].data_ptr() for p in range(16)] if with_payload else None)
+        torch.cuda.synchronize()
+        for p in range(16):
+            got = bufs[p].cpu().numpy().view(keys.dtype)
+            lo = p % 5 + 1
+            idx = np.flatnonzero(pos == p)
+            assert np.array_equal(got[lo:lo + counts[p]], keys[idx]), p
+            assert (got[:lo].view(signed or keys.dtype) == -7).all() and (got[lo + counts[p]:].view(signed or keys.dtype) == -7).all()   # nothing outside
+            if with_payload:
+                assert np.array_equal(pbufs[p].cpu().numpy()[lo:lo + counts[p]], idx.astype(np.int32)), p
+        with pytest.raises(rsx.RadixSortError):          # the count was consumed
+            e.partition_scatter_waves_peer(tk.data_ptr(), n, [bufs[p].data_ptr() for p in range(16)], pay.data_ptr() if with_payload else None,
+                                           [pbufs[p].data_ptr() for p in range(16)] if with_payload else None)
+        e.partition_count_waves(tk.data_ptr(), n, world)
+        with pytest.raises(rsx.RadixSortError):          # a null destination
+            e.partition_scatter_waves_peer(tk.data_ptr(), n, [0] * 16, pay.data_ptr() if with_payload else None, [0] * 16 if with_payload else None)
+
+
+@pytest.mark.parametrize("dtype,with_payload,world,radix_bits", [("uint32", False, 8, 4), ("int64", True, 4, 4), ("uint64", True, 2, 8), ("uint32", True, 16, 4)])
+def test_peer_store_exchange_thread_ranks(rsx, oracle, dtype, with_payload, world, radix_bits):
+    """strategy="waves-p2p" with ranks as threads of one process (the receive buffers are addressed by their pointers): the
+    scatter kernels write straight into the owners' receive buffers, one all_reduce closes the exchange, the local sorts
+    follow; three steps in a row reuse the buffers.  Rank-order concatenation = the stable sort of everything."""
+    import torch
+    from radix_sort_amd.distributed import ShardedSorter
+    n = 150001
+    full = oracle.dataset("SeededUniform", dtype, n * world, seed=41)
+    hub = _Loopback(world)
+    results, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            shard = full[rank * n:(rank + 1) * n].copy()
+            signed = {"uint32": np.int32, "uint64": np.int64}.get(np.dtype(dtype).name)
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                keys = torch.from_numpy(shard.view(signed) if signed else shard).cuda()
+                pay = torch.arange(rank * n, (rank + 1) * n, dtype=torch.int32, device="cuda") if with_payload else None
+                obuf = torch.empty(2 * n, dtype=keys.dtype, device="cuda")
+                opay = torch.empty(2 * n, dtype=torch.int32, device="cuda") if with_payload else None
+                with rsx.Engine(dtype, 2 * n, payload=with_payload) as eng:
+                    eng.set_stream(stream.cuda_stream)
+                    if radix_bits != 4:
+                        eng.set_option(rsx.OPT_RADIX_BITS, radix_bits)
+                    sorter = ShardedSorter(eng, rank, world, np.dtype(dtype).itemsize * 8, hub.view(rank), strategy="waves-p2p")
+                    sorter.setup_peer_exchange(2 * n, keys.device, with_payload)
+                    try:
+                        for _ in range(3):
+                            n_local = sorter.sort(keys, None, None, pay, None, None, obuf, opay)
+                        eng.sync()
+                        assert sorter.result_in_out and sorter.last_path == "waves-p2p"
+                        assert set(sorter.timeline_ms()) <= {"count+plan", "scatter", "fence", "local_sort"}
+                        results[rank] = (obuf[:n_local].cpu().numpy().view(np.dtype(dtype)), opay[:n_local].cpu().numpy().view(np.uint32) if with_payload else None)
+                    finally:
+                        hub.barrier.wait()                   # nobody frees a buffer a peer may still be writing into
+                        sorter.close_peer_exchange()
+        except Exception as exc:   # noqa: BLE001 - surface in the main thread
+            errors.append(exc)
+            hub.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert np.array_equal(np.concatenate([r[0] for r in results]), np.sort(full, kind="stable"))
+    if with_payload:
+        assert np.array_equal(np.concatenate([r[1] for r in results]), np.argsort(full, kind="stable").astype(np.uint32))
+
+
+@pytest.mark.parametrize("ranks,extra", [(2, ["--total-log2-keys", "23"]), (4, ["--total-log2-keys", "24", "--dtype", "uint64", "--payload"])])
+def test_bench_peer_store_exchange_between_rank_processes(ranks, extra):
+    """RSX_STRATEGY=waves-p2p with every rank a PROCESS of its own (bench.py's launcher, all ranks on the box's one GPU): the
+    receive buffers travel as IPC handles (rsx_peer_alloc / rsx_peer_open) and the scatter kernel of one process stores into
+    memory another process allocated; everything gathered on rank 0 and compared with a host sort."""
+    line = _bench(["--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"] + extra, {"RSX_BENCH_SHARED_GPU": "1", "RSX_STRATEGY": "waves-p2p"})
+    assert line["n_gpus"] == ranks and line["rehearsal"] is True
+    assert line["config"]["verified"].startswith("bit-exact vs a host sort of all")
+    assert "[waves-p2p]" in line["config"]["parallelism"] and "peer stores" in line["config"]["parallelism"]
+    assert set(line["sharded_phases_ms"]) - {"note"} <= {"count+plan", "scatter", "fence", "local_sort"}

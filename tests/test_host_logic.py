@@ -55,6 +55,27 @@ def test_product_uniform_dataset_matches_oracle_standin(hostlib, oracle):
         assert np.array_equal(a, oracle.dataset("SeededUniform", dt, 4099, seed))
 
 
+def test_contiguous_shards_concatenate_to_the_one_dataset(hostlib):
+    """rsxh_dataset_fill_shard: the ranks of a sharded sort each produce their contiguous shard of ONE dataset (BASELINE config 4:
+    `Random` sharded contiguously — std::mt19937::discard(rank * n), Dataset.h:110-120); the shards in rank order are the dataset."""
+    hostlib.rsxh_dataset_fill_shard.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]
+    hostlib.rsxh_dataset_fill_shard.restype = C.c_int
+    total, seed = 10007, 77
+    for kind in KINDS:
+        for dt in DTYPES:
+            whole = _fill(hostlib, kind, dt, total, seed)
+            for world in (1, 3, 8):
+                cuts = [total * r // world for r in range(world + 1)]
+                parts = []
+                for a, b in zip(cuts, cuts[1:]):
+                    out = np.empty(b - a, dtype=dt)
+                    assert hostlib.rsxh_dataset_fill_shard(KINDS[kind], DTYPES[dt], out.ctypes.data, a, b - a, total, seed) == 0
+                    parts.append(out)
+                assert np.array_equal(np.concatenate(parts), whole), (kind, dt, world)
+    out = np.empty(4, dtype=np.uint32)
+    assert hostlib.rsxh_dataset_fill_shard(3, 0, out.ctypes.data, total - 2, 4, total, 0) != 0      # past the end
+
+
 def test_resize_rounds_to_1024(hostlib):
     # RadixSortGPU::Resize (reference src/RadixSortGPU.cpp:288-297)
     for nn, want in [(0, 0), (1, 1024), (1000, 1024), (1024, 1024), (1025, 2048), (1 << 25, 1 << 25), ((1 << 28) + 1, (1 << 28) + 1024)]:
