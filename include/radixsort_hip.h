@@ -80,6 +80,13 @@ typedef enum rsx_option {
                                  stream of the same device; engines that scan at the same time share that budget — a caller running k > 2
                                  of them concurrently on one device sets resident / k here.  Values are clamped to what is resident; -1 =
                                  default; 0 = never.  Larger tables take scan #1, then scan #2 + paste (two launches), same table. */
+    RSX_OPT_INLINE_SCAN = 17, /* (default 0: measured 5-20 % slower than the scan launch it removes, kept as a tested option) 1: inside rsx_sort, tables beyond the self-scan and of at most RSX_OPT_INLINE_SCAN_MAX_GROUPS scan groups get no
+                                 scan launch of their own: the first workgroups of every reorder launch scan the pass's table (the fused scan's
+                                 workgroup body, entries published write-through with a per-group ready word) before they turn to their tiles,
+                                 and every workgroup waits for the word of its tile's group while it ranks its keys.  passes + 1 dependent
+                                 launches instead of 2 passes + 1.  Same table, same result; not taken while RSX_OPT_PROFILE is 1, with
+                                 RSX_OPT_GRAPH, or beyond RSX_OPT_FUSED_SCAN_MAX_GROUPS (the same co-residency rule). */
+    RSX_OPT_INLINE_SCAN_MAX_GROUPS = 18, /* (default 64 = 2^26 keys) largest table, in scan groups, that takes the inline scan */
     RSX_OPT_DEBUG_RAISE_SCAN_TIMEOUT = 16, /* tests only: enqueue the store a timed-out fused scan makes (see rsx_check_status) */
     RSX_OPT_RADIX_BITS = 10,  /* digit width of the rsx_sort chain: 4 (default, the reference's _NUM_BITS_PER_RADIX, src/Parameters.h:25) or 8.
                                  With 8 a pass sorts by a whole byte (two stable 4-bit rounds inside LDS, one scatter of up to

@@ -130,6 +130,10 @@ struct rsx_engine {
     uint32_t scan_epoch = 0;                    // launch count of the fused scan (tags the granules; never 0)
     uint32_t* temp = nullptr;                   // grand total of scan #2
     uint32_t* counts_next = nullptr;            // look-ahead histogram of the next pass, [tile][digit]
+    uint32_t* counts_next2 = nullptr;           // inline-scan chain: the second of two alternating count buffers (the scan of a launch reads one, its look-ahead adds into the other)
+    uint32_t* scan_ready = nullptr;             // inline-scan chain: [group] = epoch of the launch whose table entries of that group are published
+    int inline_scan = 0;                        // rsx_sort: mid-size sorts run the table scan inside the reorder launch (RSX_OPT_INLINE_SCAN, env RSX_INLINE_SCAN); measured SLOWER than the scan launch (profiles/r03_tuning_log.md §4): off
+    uint32_t inline_scan_max_groups = 64;       // ... for tables of at most this many scan groups (2^26 keys; env RSX_INLINE_SCAN_MAX_GROUPS), never beyond fused_scan_limit
 #ifdef RSX_STAMPS
     unsigned long long* stamps = nullptr;       // diagnostic build: 16 phase stamps per tile of ONE chosen launch
     int stamp_pass = -1;                        // env RSX_STAMP_PASS: the pass whose reorder launch writes them
@@ -153,6 +157,17 @@ struct rsx_engine {
     uint32_t* starts_dev = nullptr;             // 16 bucket starts (rsx_partition)
     uint32_t* starts_host = nullptr;            // pinned mirror
     uint64_t table_cap = 0;
+    // Large buffers may be backed by separately created physical chunks mapped into one virtual range in a shuffled order
+    // (RSX_ALLOC_MODE, big_alloc below): which physical pages a buffer gets decides how the scatter's 16..512 write fronts —
+    // a power of two apart for 2^k uniform keys — fall onto L2 sets / HBM banks (profiles/r03_tuning_log.md §5).
+    struct BigBuf {
+        void* base = nullptr;
+        size_t size = 0;
+        std::vector<hipMemGenericAllocationHandle_t> chunks;     // empty: plain hipMalloc
+    };
+    std::vector<BigBuf> big;
+    int alloc_mode = 0;         // 0 hipMalloc; 1 chunks mapped in creation order; 2 chunks mapped in a shuffled order (env RSX_ALLOC_MODE)
+    size_t alloc_chunk = 0;     // chunk bytes (env RSX_ALLOC_CHUNK_MB; 0 = the recommended granularity)
     unsigned long long* peer_dev = nullptr;     // peer-store exchange: 16 key + 16 payload destination addresses (allocated on first use)
 
     hipStream_t stream = nullptr;
@@ -750,6 +765,89 @@ int sort8_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext
 
 #endif
 
+// Reorder launch with the table scan inside it (rsx::InlineScanArgs): LOOKAHEAD counts the next pass into `next_counts`.
+template <typename Key, bool PAYLOAD, bool LOOKAHEAD>
+int launch_reorder_inline(rsx_engine* e, const void* in, void* out, const uint32_t* pin, uint32_t* pout, uint64_t count, int shift, int next_shift,
+                          uint32_t* next_counts, const rsx::InlineScanArgs& iscan)
+{
+    using L = rsx::ReorderLayout<Key, kTileThreads, kKeysPerThread, (RSX_ALIAS_COUNTERS != 0)>;
+    static_assert(L::BYTES >= sizeof(rsx::FusedScanLds), "the scan's scratch lies over the reorder's dynamic LDS");
+    static bool allowed = false;       // (per instantiation)
+    if (!allowed) {
+        RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder_kernel<Key, kTileThreads, kKeysPerThread, PAYLOAD, LOOKAHEAD, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L::BYTES)), RSX_INITIALIZATION_FAILED);
+        allowed = true;
+    }
+    const Grid g = grid_for(e, count);
+    e->last_in = in;
+    e->last_shift = shift;
+    Bracket b(e, PH_REORDER);
+    hipLaunchKernelGGL((rsx::reorder_kernel<Key, kTileThreads, kKeysPerThread, PAYLOAD, LOOKAHEAD, false, true>), dim3(g.blocks), dim3(kTileThreads), L::BYTES, e->stream,
+                       static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->table, count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip_mask<Key>(e),
+                       static_cast<uint32_t>(RSX_RADIX - 1), next_counts, next_shift, static_cast<const uint32_t*>(nullptr), Key{0}, Key{0}, split_set<Key>(e, 0),
+                       rsx::SelfScanArgs{nullptr, nullptr, nullptr}, rsx::PeerArgs{nullptr, nullptr}, iscan);
+    RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
+    return RSX_OK;
+}
+
+// Mid-size tables (beyond the self-scan, at most inline_scan_max_groups scan groups): one histogram launch, then ONE launch per pass —
+// the first workgroups of every reorder launch scan the pass's table before they turn to their own tiles (rsx::InlineScanArgs), so the
+// chain is passes + 1 dependent launches instead of 2 passes + 1.  Two count buffers alternate between "scanned (and zeroed) by this
+// launch" and "filled by this launch's look-ahead".
+template <typename Key>
+int sort_inline_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext_perm, uint64_t count)
+{
+    const uint32_t ntiles = static_cast<uint32_t>(e->ntiles(count));
+    const uint32_t ngroups = (ntiles + rsx::kScanTiles - 1) / rsx::kScanTiles;
+    const void* in = ext_keys ? ext_keys : e->keys[e->cur];
+    const uint32_t* pin = e->has_payload ? (ext_keys ? ext_perm : e->perm[e->cur]) : nullptr;
+    int dst = ext_keys ? e->cur : (e->cur ^ 1);
+    Bracket whole(e, PH_TOTAL);
+    const size_t rows = static_cast<size_t>(ntiles) * RSX_RADIX * 4;
+    RSX_TRY(hipMemsetAsync(e->counts_next, 0, rows, e->stream), RSX_CALCULATION_FAILED);      // (a sort that failed midway may have left counts)
+    RSX_TRY(hipMemsetAsync(e->counts_next2, 0, rows, e->stream), RSX_CALCULATION_FAILED);
+    int rc = launch_histogram<Key>(e, in, count, e->first_pass * RSX_RADIX_BITS, RSX_RADIX - 1);
+    if (rc != RSX_OK) return rc;
+    uint32_t* bufs[2] = {e->counts_next, e->counts_next2};
+    int filled = 1;                      // bufs[filled] holds the counts the NEXT launch scans (none before the first pass); its look-ahead fills the other
+    for (int pass = e->first_pass; pass < e->last_pass; ++pass) {
+        const bool first = pass == e->first_pass, last = pass + 1 == e->last_pass;
+        const bool to_caller = e->final_keys_out && last;
+        void* out = to_caller ? e->final_keys_out : e->keys[dst];
+        uint32_t* pout = e->has_payload ? (to_caller ? e->final_perm_out : e->perm[dst]) : nullptr;
+        const int shift = pass * RSX_RADIX_BITS;
+        if (++e->scan_epoch == 0) e->scan_epoch = 1;
+        const rsx::InlineScanArgs iscan{e->gsums, e->globsum2, e->temp, bufs[filled], e->scan_ready, e->scan_timeout, e->scan_epoch, ngroups, first ? 0 : 1};
+        uint32_t* next = bufs[filled ^ 1];
+        if (e->has_payload) {
+            rc = last ? launch_reorder_inline<Key, true, false>(e, in, out, pin, pout, count, shift, 0, next, iscan)
+                      : launch_reorder_inline<Key, true, true>(e, in, out, pin, pout, count, shift, shift + RSX_RADIX_BITS, next, iscan);
+        } else {
+            rc = last ? launch_reorder_inline<Key, false, false>(e, in, out, nullptr, nullptr, count, shift, 0, next, iscan)
+                      : launch_reorder_inline<Key, false, true>(e, in, out, nullptr, nullptr, count, shift, shift + RSX_RADIX_BITS, next, iscan);
+        }
+        if (rc != RSX_OK) return rc;
+        filled ^= 1;
+        in = out;
+        pin = pout;
+        dst ^= 1;
+    }
+    e->counted_keys = nullptr;
+    e->globsum_live = e->globsum2;
+    e->table_valid = true;
+    e->globsum_valid = true;
+    if (in == e->keys[0] || in == e->keys[1]) e->cur = (in == e->keys[0]) ? 0 : 1;
+    e->result_external = e->final_keys_out != nullptr;
+    if (e->final_keys_out) {
+        e->result_keys = e->final_keys_out;
+        e->result_perm = e->has_payload ? e->final_perm_out : nullptr;
+    } else {
+        e->result_keys = e->keys[e->cur];
+        e->result_perm = e->has_payload ? e->perm[e->cur] : nullptr;
+    }
+    return RSX_OK;
+}
+
 template <typename Key>
 int sort_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext_perm, uint64_t count)
 {
@@ -785,6 +883,15 @@ int sort_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext_
     if (e->self_scan && e->lookahead && !e->fold_paste && count > static_cast<uint64_t>(kTileKeys) && e->ntiles(count) <= e->self_scan_max && e->first_pass < e->last_pass) {
         if (count <= e->small_tile_max_keys) return sort_selfscan_enqueue<Key, kSmallKeysPerThread>(e, ext_keys, ext_perm, count);
         return sort_selfscan_enqueue<Key>(e, ext_keys, ext_perm, count);
+    }
+    {
+        const uint32_t groups = static_cast<uint32_t>((e->ntiles(count) + rsx::kScanTiles - 1) / rsx::kScanTiles);
+        // (profile mode 1 keeps the separate scan launches: timeScan / timePaste would otherwise be empty; a captured graph would replay a stale epoch)
+        if (e->inline_scan && e->lookahead && e->fused_scan && !e->fold_paste && !e->use_graph && e->profile != 1 && e->scan_zeroes && count > 0 &&
+            e->first_pass < e->last_pass && e->ntiles(count) > static_cast<uint64_t>(rsx::kSmallScanMaxTiles) &&
+            groups <= std::min(e->inline_scan_max_groups, e->fused_scan_limit)) {
+            return sort_inline_enqueue<Key>(e, ext_keys, ext_perm, count);
+        }
     }
     // Ping-pong.  With external input the first pass reads the caller's buffer (never
     // written) and the chain continues inside the engine's two buffers.
@@ -962,6 +1069,90 @@ int bind_device(const rsx_engine* e, int status)
     return RSX_OK;
 }
 
+// ---- large-buffer allocation ----------------------------------------------------------------------------------------------
+hipError_t big_alloc(rsx_engine* e, void** out, size_t bytes)
+{
+    *out = nullptr;
+    rsx_engine::BigBuf b;
+    if (e->alloc_mode == 0 || bytes < (64u << 20)) {
+        const hipError_t err = hipMalloc(&b.base, bytes);
+        if (err != hipSuccess) return err;
+        b.size = bytes;
+        e->big.push_back(b);
+        *out = b.base;
+        return hipSuccess;
+    }
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = e->device;
+    size_t gran = 0;
+    hipError_t err = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended);
+    if (err != hipSuccess) return err;
+    // chunks of at least 2 MiB and at most 1024 of them per buffer: the first version took the recommended granularity as it came
+    // (small on this stack) and spent minutes creating and mapping chunks (profiles/r03_fault_vmm_alloc_silence.txt)
+    size_t chunk = e->alloc_chunk ? e->alloc_chunk : (static_cast<size_t>(32) << 20);
+    chunk = std::max(chunk, static_cast<size_t>(2) << 20);
+    chunk = std::max(chunk, (bytes + 1023) / 1024);
+    chunk = (chunk + gran - 1) / gran * gran;
+    const size_t nchunks = (bytes + chunk - 1) / chunk;
+    if (std::getenv("RSX_DEBUG_ALLOC")) std::fprintf(stderr, "[radixsort_hip] big_alloc: %zu bytes as %zu chunks of %zu (granularity %zu), mode %d\n", bytes, nchunks, chunk, gran, e->alloc_mode);
+    b.size = nchunks * chunk;
+    if ((err = hipMemAddressReserve(&b.base, b.size, chunk, nullptr, 0)) != hipSuccess) return err;
+    auto undo = [&](hipError_t why) {
+        for (auto h : b.chunks) (void)hipMemRelease(h);
+        (void)hipMemAddressFree(b.base, b.size);
+        return why;
+    };
+    for (size_t i = 0; i < nchunks; ++i) {
+        hipMemGenericAllocationHandle_t h;
+        if ((err = hipMemCreate(&h, chunk, &prop, 0)) != hipSuccess) return undo(err);
+        b.chunks.push_back(h);
+    }
+    std::vector<size_t> order(nchunks);
+    for (size_t i = 0; i < nchunks; ++i) order[i] = i;
+    if (e->alloc_mode == 2) {
+        // a fixed pseudo-random permutation (xorshift; the same for every buffer of the same length: reproducible runs)
+        unsigned long long x = 0x9E3779B97F4A7C15ull ^ (nchunks * 0x100000001B3ull);
+        for (size_t i = nchunks - 1; i > 0; --i) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            std::swap(order[i], order[static_cast<size_t>(x % (i + 1))]);
+        }
+    }
+    for (size_t i = 0; i < nchunks; ++i) {
+        if ((err = hipMemMap(static_cast<char*>(b.base) + i * chunk, chunk, 0, b.chunks[order[i]], 0)) != hipSuccess) {
+            if (i) (void)hipMemUnmap(b.base, i * chunk);
+            return undo(err);
+        }
+    }
+    hipMemAccessDesc acc = {};
+    acc.location.type = hipMemLocationTypeDevice;
+    acc.location.id = e->device;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    if ((err = hipMemSetAccess(b.base, b.size, &acc, 1)) != hipSuccess) {
+        (void)hipMemUnmap(b.base, b.size);
+        return undo(err);
+    }
+    e->big.push_back(b);
+    *out = b.base;
+    return hipSuccess;
+}
+
+bool big_free(rsx_engine* e, void* p)
+{
+    if (!p) return true;
+    for (size_t i = 0; i < e->big.size(); ++i) {
+        if (e->big[i].base != p) continue;
+        rsx_engine::BigBuf b = e->big[i];
+        e->big.erase(e->big.begin() + static_cast<long>(i));
+        if (b.chunks.empty()) return hipFree(p) == hipSuccess;
+        bool ok = hipMemUnmap(b.base, b.size) == hipSuccess;
+        for (auto h : b.chunks) ok = (hipMemRelease(h) == hipSuccess) && ok;
+        return (hipMemAddressFree(b.base, b.size) == hipSuccess) && ok;
+    }
+    return hipFree(p) == hipSuccess;
+}
+
 }  // namespace
 
 #define RSX_BY_KEY(e, call32, call64) ((e)->key_bytes == 4 ? (call32) : (call64))
@@ -1024,6 +1215,8 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
     e->n = 0;
     e->last_pass = static_cast<int>(e->passes());
     for (auto& s : e->stats) stat_reset(s);
+    if (const char* env = std::getenv("RSX_ALLOC_MODE")) e->alloc_mode = std::max(0, std::min(2, std::atoi(env)));
+    if (const char* env = std::getenv("RSX_ALLOC_CHUNK_MB")) e->alloc_chunk = static_cast<size_t>(std::max(0, std::atoi(env))) << 20;
     if (const char* env = std::getenv("RSX_XCD_REMAP")) e->xcd_remap = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_XCD_PHASE")) e->xcd_phase = std::atoll(env);
     if (const char* env = std::getenv("RSX_REVERSE_ODD")) e->reverse_odd = std::atoi(env) != 0;
@@ -1039,6 +1232,8 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
     if (const char* env = std::getenv("RSX_RADIX8_MIN_KEYS")) e->radix8_min_keys = std::max<uint64_t>(std::strtoull(env, nullptr, 10), kTileKeys);
     if (const char* env = std::getenv("RSX_PASTE_SCAN")) e->paste_scan = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_FUSED_SCAN")) e->fused_scan = std::atoi(env) != 0;
+    if (const char* env = std::getenv("RSX_INLINE_SCAN")) e->inline_scan = std::atoi(env) != 0;
+    if (const char* env = std::getenv("RSX_INLINE_SCAN_MAX_GROUPS")) e->inline_scan_max_groups = static_cast<uint32_t>(std::max(0, std::atoi(env)));
     if (const char* env = std::getenv("RSX_FOLD_PASTE")) e->fold_paste = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_SCAN_ZEROES")) e->scan_zeroes = std::atoi(env) != 0;
 
@@ -1054,9 +1249,9 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
 
     const size_t key_buf = static_cast<size_t>(capacity) * key_bytes;
     for (int i = 0; i < 2; ++i) {
-        if ((err = hipMalloc(&e->keys[i], key_buf)) != hipSuccess) return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(keys)", err);
+        if ((err = big_alloc(e, &e->keys[i], key_buf)) != hipSuccess) return bail(RSX_INITIALIZATION_FAILED, "allocation of a key buffer", err);
         if (e->has_payload) {
-            if ((err = hipMalloc(reinterpret_cast<void**>(&e->perm[i]), static_cast<size_t>(capacity) * 4)) != hipSuccess)
+            if ((err = big_alloc(e, reinterpret_cast<void**>(&e->perm[i]), static_cast<size_t>(capacity) * 4)) != hipSuccess)
                 return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(permutations)", err);
         }
     }
@@ -1070,6 +1265,18 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
         return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(histograms)", err);
     if ((err = hipMalloc(reinterpret_cast<void**>(&e->counts_next), table_alloc)) != hipSuccess)
         return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(look-ahead counts)", err);
+    {
+        // the inline-scan chain serves tables of at most kFusedScanMaxGroups groups: its second count buffer need not be larger
+        const size_t second = std::min<size_t>(table_alloc, static_cast<size_t>(rsx::kFusedScanMaxGroups) * rsx::kScanTiles * RSX_RADIX * 4);
+        if ((err = hipMalloc(reinterpret_cast<void**>(&e->counts_next2), second)) != hipSuccess)
+            return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(second look-ahead counts)", err);
+        if ((err = hipMemsetAsync(e->counts_next2, 0, second, e->stream)) != hipSuccess)
+            return bail(RSX_INITIALIZATION_FAILED, "hipMemsetAsync(second look-ahead counts)", err);
+        if ((err = hipMalloc(reinterpret_cast<void**>(&e->scan_ready), rsx::kFusedScanMaxGroups * 4)) != hipSuccess)
+            return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(scan ready words)", err);
+        if ((err = hipMemsetAsync(e->scan_ready, 0, rsx::kFusedScanMaxGroups * 4, e->stream)) != hipSuccess)
+            return bail(RSX_INITIALIZATION_FAILED, "hipMemsetAsync(scan ready words)", err);
+    }
 #ifdef RSX_STAMPS
     if ((err = hipMalloc(reinterpret_cast<void**>(&e->stamps), e->ntiles(capacity) * 16 * 8)) != hipSuccess)
         return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(stamps)", err);
@@ -1174,11 +1381,13 @@ int rsx_destroy(rsx_engine* e)
     for (hipEvent_t ev : e->pool) (void)hipEventDestroy(ev);
     for (const GraphEntry& g : e->graphs) (void)hipGraphExecDestroy(g.exec);
     for (int i = 0; i < 2; ++i) {
-        if (e->keys[i] && hipFree(e->keys[i]) != hipSuccess) status = RSX_CLEANUP_FAILED;
-        if (e->perm[i] && hipFree(e->perm[i]) != hipSuccess) status = RSX_CLEANUP_FAILED;
+        if (!big_free(e, e->keys[i])) status = RSX_CLEANUP_FAILED;
+        if (!big_free(e, e->perm[i])) status = RSX_CLEANUP_FAILED;
     }
     if (e->table && hipFree(e->table) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->counts_next && hipFree(e->counts_next) != hipSuccess) status = RSX_CLEANUP_FAILED;
+    if (e->counts_next2 && hipFree(e->counts_next2) != hipSuccess) status = RSX_CLEANUP_FAILED;
+    if (e->scan_ready && hipFree(e->scan_ready) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->globsum && hipFree(e->globsum) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->globsum2 && hipFree(e->globsum2) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->temp && hipFree(e->temp) != hipSuccess) status = RSX_CLEANUP_FAILED;
@@ -1253,6 +1462,11 @@ int rsx_set_option(rsx_engine* e, int option, int64_t value)
     case RSX_OPT_SMALL_SCAN: e->small_scan = value != 0; return RSX_OK;
     case RSX_OPT_TILE_SORT: e->tile_sort = value != 0; return RSX_OK;
     case RSX_OPT_FUSED_SCAN: e->fused_scan = value != 0; return RSX_OK;
+    case RSX_OPT_INLINE_SCAN: e->inline_scan = value != 0; return RSX_OK;
+    case RSX_OPT_INLINE_SCAN_MAX_GROUPS:
+        if (value < 0) return fail(RSX_CALCULATION_FAILED, "rsx_set_option: negative group count");
+        e->inline_scan_max_groups = static_cast<uint32_t>(std::min<int64_t>(value, rsx::kFusedScanMaxGroups));
+        return RSX_OK;
     case RSX_OPT_FUSED_SCAN_MAX_GROUPS:
         // never beyond what the occupancy query says is resident at once (nor the granule buffer): -1 restores the default
         if (value < -1) return fail(RSX_CALCULATION_FAILED, "rsx_set_option: negative group count");

@@ -411,16 +411,22 @@ __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREAD
             for (int r = 0; r < KPT; ++r) {
                 g[r] += tid + static_cast<uint32_t>(r) * THREADS;
             }
+            if (flip != Key{0}) {        // (uniform: unsigned keys skip the flip on the way out as on the way in)
+#pragma unroll
+                for (int r = 0; r < KPT; ++r) {
+                    okey[r] ^= flip;
+                }
+            }
             if (full) {
 #pragma unroll
                 for (int r = 0; r < KPT; ++r) {
-                    out[g[r]] = static_cast<Key>(okey[r] ^ flip);
+                    out[g[r]] = okey[r];
                 }
             } else {
 #pragma unroll
                 for (int r = 0; r < KPT; ++r) {
                     if (static_cast<uint32_t>(r) * THREADS + tid < valid) {
-                        out[g[r]] = static_cast<Key>(okey[r] ^ flip);
+                        out[g[r]] = okey[r];
                     }
                 }
             }
@@ -722,10 +728,16 @@ __global__ __launch_bounds__(THREADS, (Reorder8V2Layout<Key, THREADS, KPT, PAYLO
     for (int r = 0; r < KPT; ++r) {
         g[r] += tid + static_cast<uint32_t>(r) * THREADS;
     }
+    if (flip != Key{0}) {        // (uniform)
+#pragma unroll
+        for (int r = 0; r < KPT; ++r) {
+            okey[r] ^= flip;
+        }
+    }
     if (full) {
 #pragma unroll
         for (int r = 0; r < KPT; ++r) {
-            out[g[r]] = static_cast<Key>(okey[r] ^ flip);
+            out[g[r]] = okey[r];
         }
         if constexpr (PAYLOAD) {
 #pragma unroll
@@ -737,7 +749,7 @@ __global__ __launch_bounds__(THREADS, (Reorder8V2Layout<Key, THREADS, KPT, PAYLO
 #pragma unroll
         for (int r = 0; r < KPT; ++r) {
             if (static_cast<uint32_t>(r) * THREADS + tid < valid) {
-                out[g[r]] = static_cast<Key>(okey[r] ^ flip);
+                out[g[r]] = okey[r];
                 if constexpr (PAYLOAD) {
                     pout[g[r]] = pay[r];
                 }

@@ -189,6 +189,24 @@ struct PeerArgs {
     const unsigned long long* pays;
 };
 
+// Inline table scan (mid-size sorts, INLINE_SCAN kernels): the launch has no scan kernel in front of it.  Its first `ngroups`
+// workgroups (in dispatch order the first to start) each scan one group of 256 tiles of THIS pass's raw counts before turning to their
+// own tile — the fused scan's workgroup body (fused_scan_group), with the finished table entries published write-through and a
+// per-group `ready` word; every workgroup's lane 0 polls the word of its tile's group while the other lanes rank the tile's keys, and
+// the 16 table entries of the tile are then read with sc1 loads.  One dependent launch per pass instead of two.  The scan reads (and
+// zeroes) `counts`, the look-ahead of the same launch adds into the OTHER count buffer: the two alternate from pass to pass.
+struct InlineScanArgs {
+    unsigned long long* sums;      // granules [group][16] (the fused scan's)
+    uint32_t* scanned;             // scanned group sums, as the fused scan leaves them
+    uint32_t* temp;
+    uint32_t* counts;              // raw [tile][16] counts of this pass (from_counts), handed back zeroed
+    uint32_t* ready;               // [group] = epoch once the group's table entries are published
+    uint32_t* timeout;
+    uint32_t epoch;
+    uint32_t ngroups;
+    int from_counts;               // 0: the raw counts sit in the table itself ([digit][tile], after the histogram kernel)
+};
+
 // LOOKAHEAD: while a key leaves for its slot g, the kernel also counts the key's NEXT
 // digit for the output tile g / TILE — i.e. it builds the next pass's per-tile histogram
 // (layout [tile][digit] in `next_counts`, zeroed by the host) without another pass over
@@ -199,15 +217,17 @@ struct PeerArgs {
 // (mask 15) and the next digit the field at `next_shift`.  It works on RAW fields (no sign flip per
 // key): the sign bit only ever toggles the top bit of the top digit, which is folded into where the
 // counters, the run bases and the flushed counts are PLACED (flip_cur / flip_next below).
-template <typename Key, int THREADS, int KPT, bool PAYLOAD, bool LOOKAHEAD, bool RANGED = false>
+template <typename Key, int THREADS, int KPT, bool PAYLOAD, bool LOOKAHEAD, bool RANGED = false, bool INLINE_SCAN = false>
 __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYLOAD, RANGED>())) void reorder_kernel(const Key* __restrict__ in, Key* __restrict__ out,
                                                            const uint32_t* __restrict__ pin, uint32_t* __restrict__ pout,
-                                                           const uint32_t* __restrict__ table, uint64_t n, uint32_t ntiles,
+                                                           const uint32_t* table, uint64_t n, uint32_t ntiles,
                                                            uint32_t tiles_per_xcd, int remap, int shift, Key flip, uint32_t mask,
                                                            uint32_t* __restrict__ next_counts, int next_shift,
                                                            const uint32_t* __restrict__ globsum, Key lo, Key mul,
-                                                           SplitSet<Key> split, SelfScanArgs self, PeerArgs peer = PeerArgs{nullptr, nullptr})
+                                                           SplitSet<Key> split, SelfScanArgs self, PeerArgs peer = PeerArgs{nullptr, nullptr},
+                                                           InlineScanArgs iscan = InlineScanArgs{})
 {
+    static_assert(!INLINE_SCAN || (!RANGED && THREADS == kScanTiles), "the inline scan is the fused scan's workgroup: 256 threads, rsx_sort's passes only");
     using L = ReorderLayout<Key, THREADS, KPT, (!RANGED && RSX_ALIAS_COUNTERS != 0)>;
     static_assert(!(RANGED && LOOKAHEAD), "the ranged bucket function is for the one-pass partition only");
     constexpr bool RAW = LOOKAHEAD;                 // digits are raw 4-bit fields; the sign flip lives in the placement
@@ -226,6 +246,14 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
     uint32_t* self_base = self_part + (THREADS / kWave) * 2 * kRadix;      // [digit]
 
     const uint32_t tid = threadIdx.x;
+    // (before the surplus workgroups of the XCD mapping leave: a scanning workgroup scans whether or not it has a tile of its own)
+    if constexpr (INLINE_SCAN) {
+        if (blockIdx.x < iscan.ngroups) {           // workgroup-uniform
+            fused_scan_group<true, true>(*reinterpret_cast<FusedScanLds*>(smem), blockIdx.x, const_cast<uint32_t*>(table), iscan.sums, iscan.scanned, iscan.temp,
+                                         ntiles, iscan.ngroups, iscan.counts, iscan.from_counts != 0, iscan.epoch, iscan.timeout, iscan.ready);
+            __syncthreads();                        // the scratch is this workgroup's dynamic LDS again
+        }
+    }
     const uint32_t slot_tile = tile_of_block(blockIdx.x, tiles_per_xcd, remap & ~2);
     if (slot_tile >= ntiles) {
         return;
@@ -303,7 +331,7 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
 #define RSX_SELF_SCAN_KERNEL 1
 #endif
     const bool self_scan = RSX_SELF_SCAN_KERNEL && !RANGED && self.counts != nullptr;      // wave-uniform
-    if (rake_head && !self_scan) {
+    if (rake_head && !self_scan && !INLINE_SCAN) {
         const uint64_t e_lo = static_cast<uint64_t>(hl) * ntiles + tile;
         const uint64_t e_hi = static_cast<uint64_t>(hl + 8) * ntiles + tile;
         first_lo = table[e_lo];
@@ -519,7 +547,28 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
         }
     };
     RSX_STAMP(2);
+    if constexpr (INLINE_SCAN) {
+        // lane 0 waits for the table entries of the tile's scan group while the other waves are still ranking (one poller per
+        // workgroup, relaxed sc1 loads, bounded); the barrier below is the one the other waves join before they load
+        if (tid == 0) {
+            const uint32_t* word = iscan.ready + tile / kScanTiles;
+            uint32_t spins = 0;
+            while (__hip_atomic_load((gu32*)(word), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != iscan.epoch) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1u << 22)) {
+                    __hip_atomic_store((gu32*)(iscan.timeout), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+            }
+        }
+    }
     __syncthreads();
+    if constexpr (INLINE_SCAN) {
+        if (rake_head) {
+            first_lo = __hip_atomic_load((gu32*)(table) + static_cast<uint64_t>(hl) * ntiles + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            first_hi = __hip_atomic_load((gu32*)(table) + static_cast<uint64_t>(hl + 8) * ntiles + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     RSX_STAMP(3);
 
     // ---- 3. raking scan over the 8*THREADS packed words in [digit&7][thread] order ---

@@ -225,21 +225,29 @@ constexpr int kFusedScanMaxGroups = 512;
 typedef __attribute__((address_space(1))) uint32_t gu32;
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 
-template <bool FROM_COUNTS, bool ZERO_BACK>
-__global__ __launch_bounds__(kScanTiles) void scan_fused_kernel(uint32_t* __restrict__ table, unsigned long long* sums, uint32_t* __restrict__ scanned,
-                                                                 uint32_t* __restrict__ temp, uint32_t ntiles, uint32_t ngroups,
-                                                                 uint32_t* __restrict__ counts, uint32_t epoch, uint32_t* timeout)
+// LDS scratch of one fused-scan workgroup (1 KiB).  The stand-alone kernel keeps it in static LDS; reorder_kernel's inline scan
+// (below) lays it over the start of its dynamic LDS, which is free until the tile's own work begins.
+struct FusedScanLds {
+    uint32_t wsum[kScanTiles / kWave][kRadix];
+    uint32_t part[kScanTiles / kWave][2][kRadix];
+    uint32_t dtot[kRadix], off[kRadix];
+};
+
+// One workgroup's share of the fused scan: scan group `group` (256 tiles, all 16 digits).  PUBLISH (the inline form): the finished
+// table entries leave as write-through (sc1) stores, every storing wave drains them, and after the workgroup's barrier ONE lane
+// stores `epoch` to ready[group] — the R1 hand-off of the CDNA guide (sc1 payload -> vmcnt(0) -> barrier -> sc1 flag); consumers poll
+// that word with sc1 loads and read the entries with sc1 loads.  FROM_COUNTS is a run-time (wave-uniform) flag here.
+template <bool ZERO_BACK, bool PUBLISH>
+__device__ __forceinline__ void fused_scan_group(FusedScanLds& lds, uint32_t group, uint32_t* __restrict__ table, unsigned long long* sums,
+                                                 uint32_t* __restrict__ scanned, uint32_t* __restrict__ temp, uint32_t ntiles, uint32_t ngroups,
+                                                 uint32_t* __restrict__ counts, bool from_counts, uint32_t epoch, uint32_t* timeout, uint32_t* ready)
 {
     constexpr int WAVES = kScanTiles / kWave;
-    __shared__ uint32_t wsum[WAVES][kRadix];
-    __shared__ uint32_t part[WAVES][2][kRadix];
-    __shared__ uint32_t dtot[kRadix], off[kRadix];
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-    const uint32_t group = blockIdx.x;
     const uint32_t tile = group * kScanTiles + tid;
     const bool live = tile < ntiles;
     uint32_t c[kRadix];
-    if constexpr (FROM_COUNTS) {
+    if (from_counts) {
         U32x4* row = reinterpret_cast<U32x4*>(counts + static_cast<uint64_t>(tile) * kRadix);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -269,7 +277,7 @@ __global__ __launch_bounds__(kScanTiles) void scan_fused_kernel(uint32_t* __rest
     if (lane == kWave - 1) {
 #pragma unroll
         for (int d = 0; d < kRadix; ++d) {
-            wsum[wave][d] = ex[d];
+            lds.wsum[wave][d] = ex[d];
         }
     }
     __syncthreads();
@@ -278,7 +286,7 @@ __global__ __launch_bounds__(kScanTiles) void scan_fused_kernel(uint32_t* __rest
         uint32_t before = 0;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) {
-            before += (static_cast<uint32_t>(w) < wave) ? wsum[w][d] : 0u;
+            before += (static_cast<uint32_t>(w) < wave) ? lds.wsum[w][d] : 0u;
         }
         ex[d] = before + ex[d] - c[d];
     }
@@ -287,7 +295,7 @@ __global__ __launch_bounds__(kScanTiles) void scan_fused_kernel(uint32_t* __rest
         uint32_t total = 0;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) {
-            total += wsum[w][tid];
+            total += lds.wsum[w][tid];
         }
         __hip_atomic_store((gu64*)(sums) + static_cast<uint64_t>(group) * kRadix + tid, (static_cast<unsigned long long>(epoch) << 32) | total,
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -329,8 +337,8 @@ __global__ __launch_bounds__(kScanTiles) void scan_fused_kernel(uint32_t* __rest
         tot += __shfl_xor(tot, 32);
         pre += __shfl_xor(pre, 32);
         if (lane < kRadix) {
-            part[wave][0][lane] = tot;
-            part[wave][1][lane] = pre;
+            lds.part[wave][0][lane] = tot;
+            lds.part[wave][1][lane] = pre;
         }
     }
     __syncthreads();
@@ -338,35 +346,55 @@ __global__ __launch_bounds__(kScanTiles) void scan_fused_kernel(uint32_t* __rest
         uint32_t t = 0;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) {
-            t += part[w][0][tid];
+            t += lds.part[w][0][tid];
         }
-        dtot[tid] = t;
+        lds.dtot[tid] = t;
     }
     __syncthreads();
     if (tid < kRadix) {
         uint32_t base = 0;
 #pragma unroll 1
         for (uint32_t d2 = 0; d2 < tid; ++d2) {
-            base += dtot[d2];
+            base += lds.dtot[d2];
         }
         uint32_t pr = 0;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) {
-            pr += part[w][1][tid];
+            pr += lds.part[w][1][tid];
         }
-        off[tid] = base + pr;
+        lds.off[tid] = base + pr;
         scanned[static_cast<uint64_t>(tid) * ngroups + group] = base + pr;
         if (group == 0 && tid == kRadix - 1) {
-            temp[0] = base + dtot[tid];
+            temp[0] = base + lds.dtot[tid];
         }
     }
     __syncthreads();
     if (live) {
 #pragma unroll
         for (int d = 0; d < kRadix; ++d) {
-            table[static_cast<uint64_t>(d) * ntiles + tile] = ex[d] + off[d];
+            if constexpr (PUBLISH) {
+                __hip_atomic_store((gu32*)(table) + static_cast<uint64_t>(d) * ntiles + tile, ex[d] + lds.off[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                table[static_cast<uint64_t>(d) * ntiles + tile] = ex[d] + lds.off[d];
+            }
         }
     }
+    if constexpr (PUBLISH) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains its write-through stores ...
+        __syncthreads();                                       // ... before ONE lane signals for the workgroup
+        if (tid == 0) {
+            __hip_atomic_store((gu32*)(ready) + group, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+template <bool FROM_COUNTS, bool ZERO_BACK>
+__global__ __launch_bounds__(kScanTiles) void scan_fused_kernel(uint32_t* __restrict__ table, unsigned long long* sums, uint32_t* __restrict__ scanned,
+                                                                 uint32_t* __restrict__ temp, uint32_t ntiles, uint32_t ngroups,
+                                                                 uint32_t* __restrict__ counts, uint32_t epoch, uint32_t* timeout)
+{
+    __shared__ FusedScanLds lds;
+    fused_scan_group<ZERO_BACK, false>(lds, blockIdx.x, table, sums, scanned, temp, ntiles, ngroups, counts, FROM_COUNTS, epoch, timeout, nullptr);
 }
 
 // tests only (RSX_OPT_DEBUG_RAISE_SCAN_TIMEOUT): the store a timed-out sweep makes, without the sweep

@@ -1070,3 +1070,58 @@ def test_graph_capture_with_8bit_digits_allocates_outside_the_capture(mod, oracl
                 e.upload(keys)
                 e.sort()
                 assert np.array_equal(e.download(), want)
+
+
+@pytest.mark.parametrize("dt,payload,n", [("uint32", False, (1 << 22) + 4097), ("uint32", False, (1 << 24) + 4097), ("int32", True, (1 << 23) + 11),
+                                          ("uint64", True, (1 << 22) + 8192), ("int64", False, 1 << 25), ("uint32", False, 1 << 26)])
+def test_inline_scan_equals_the_scan_launches(mod, oracle, dt, payload, n):
+    """Mid-size tables: the first workgroups of every reorder launch scan the pass's table themselves (RSX_OPT_INLINE_SCAN, one dependent
+    launch per pass) — keys, payload, final table and group sums must equal what the chain with scan launches leaves; repeated sorts
+    advance the epochs and alternate the two count buffers through both roles."""
+    keys = oracle.dataset("SeededUniform", dt, n, seed=n % 1000 + 7)
+    keys[::5] = keys[3]
+    perm = np.arange(n, dtype=np.uint32) if payload else None
+    seen = []
+    for inline in (1, 0):
+        with mod.Engine(dt, n, payload=payload) as e:
+            e.set_option(mod.OPT_INLINE_SCAN, inline)
+            e.set_option(mod.OPT_PROFILE, 2)                   # reorder launches only: how many launches a sort takes is visible in the timings
+            e.upload(keys, perm)
+            for _ in range(3):
+                e.sort()
+            e.sync()
+            rt = e.timings()
+            passes = keys.dtype.itemsize * 2
+            assert rt.reorder.n == 3 * passes
+            g = e.geometry()
+            out = e.download(want_perm=payload, hist_cap=int(g.table_len), globsum_cap=int(g.num_scan_blocks))
+            seen.append(out)
+    assert np.array_equal(seen[0][0], np.sort(keys))
+    if payload:
+        assert np.array_equal(seen[0][1], np.argsort(keys, kind="stable").astype(np.uint32))
+    for a, b in zip(seen[0], seen[1]):
+        assert np.array_equal(a, b)
+
+
+def test_inline_scan_border_and_external_buffers(mod, oracle):
+    """RSX_OPT_INLINE_SCAN_MAX_GROUPS moves the border to the chain with scan launches; the inline chain behind rsx_sort_from_to (external input
+    left untouched, partial pass range, output into a caller buffer) and on ragged sizes whose XCD mapping has surplus workgroups."""
+    import torch
+    for n in ((1 << 22) + 1, (1 << 23) + 4095, 5 * (1 << 20) + 123):
+        keys = oracle.dataset("SeededUniform", "uint32", n, seed=n % 97)
+        t = torch.from_numpy(keys.view(np.int32)).cuda()
+        dst = torch.zeros(n + 3, dtype=torch.int32, device="cuda")
+        outs = []
+        for limit in (64, 0):
+            with mod.Engine("uint32", n) as e:
+                e.set_option(mod.OPT_INLINE_SCAN, 1)
+                e.set_option(mod.OPT_INLINE_SCAN_MAX_GROUPS, limit)
+                e.set_stream(torch.cuda.current_stream().cuda_stream)
+                e.sort_from_to(t.data_ptr(), n, 0, 7, dst[3:].data_ptr())
+                e.sync()
+                outs.append(dst.cpu().numpy().view(np.uint32).copy())
+                e.sort_from(t.data_ptr(), n)
+                assert np.array_equal(e.download(), np.sort(keys))
+        assert np.array_equal(t.cpu().numpy().view(np.uint32), keys)
+        low = keys & np.uint32((1 << 28) - 1)
+        assert np.array_equal(outs[0][3:], keys[np.argsort(low, kind="stable")]) and np.array_equal(outs[0], outs[1])

@@ -635,7 +635,7 @@ def test_peer_store_exchange_thread_ranks(rsx, oracle, dtype, with_payload, worl
         assert np.array_equal(np.concatenate([r[1] for r in results]), np.argsort(full, kind="stable").astype(np.uint32))
 
 
-@pytest.mark.parametrize("ranks,extra", [(2, ["--total-log2-keys", "23"]), (4, ["--total-log2-keys", "24", "--dtype", "uint64", "--payload"])])
+@pytest.mark.parametrize("ranks,extra", [(2, ["--total-log2-keys", "23"]), (4, ["--total-log2-keys", "24", "--dtype", "uint64", "--payload", "--dataset", "RandomDistributed"])])
 def test_bench_peer_store_exchange_between_rank_processes(ranks, extra):
     """RSX_STRATEGY=waves-p2p with every rank a PROCESS of its own (bench.py's launcher, all ranks on the box's one GPU): the
     receive buffers travel as IPC handles (rsx_peer_alloc / rsx_peer_open) and the scatter kernel of one process stores into

@@ -9,7 +9,12 @@
 // their own.  Reported: kernel time with and without the look-back, the mean number of predecessors a lane had to read, and
 // the result is checked (exclusive prefix of known values).
 //
-//   hipcc --offload-arch=gfx950 -O3 tools/probes/lookback_probe.hip -o gpurun_out/lookback_probe && gpurun_out/lookback_probe
+// Round 3: `per_xcd` = 1 runs EIGHT chains instead of one: each XCD (read from HW_REG_XCC_ID, so that a chain's
+// granules really stay in one L2 wherever the dispatcher put the workgroup) draws tickets from its own word and chains only over
+// its own contiguous eighth of the tiles — the first tile of a range starts from a known base, as it would if the per-range digit
+// offsets came from a kernel boundary.  A workgroup whose XCD's range is used up takes a ticket of the emptiest other range.
+//
+//   hipcc --offload-arch=gfx950 -O3 tools/probes/lookback_probe.hip -o gpurun_out/lookback_probe && gpurun_out/lookback_probe [ntiles] [lds KiB] [per_xcd]
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -29,24 +34,40 @@ __device__ __forceinline__ void spin_work(int iters)
 
 template <int WINDOW>
 __global__ __launch_bounds__(256) void lookback_kernel(unsigned long long* status, unsigned* ticket, unsigned epoch, unsigned* excl_out, unsigned long long* depth_sum,
-                                                        int pre, int post, int do_lookback, unsigned* timeout)
+                                                        int pre, int post, int do_lookback, unsigned* timeout, unsigned per_range)
 {
     extern __shared__ unsigned smem[];
     __shared__ unsigned s_tile;
     const unsigned tid = threadIdx.x;
     if (tid == 0) {
-        s_tile = atomicAdd(ticket, 1u);
+        if (per_range == 0) {
+            s_tile = atomicAdd(ticket, 1u);
+        } else {
+            // one ticket word per XCD (64 bytes apart); a range that is used up sends the workgroup to the next one
+            unsigned x = __builtin_amdgcn_s_getreg((20u /* HW_REG_XCC_ID */) | (0u << 6) | ((4u - 1u) << 11)) & 7u;
+            unsigned t = per_range;
+            for (int tries = 0; tries < 8 && t >= per_range; ++tries, x = (x + 1u) & 7u) {
+                t = atomicAdd(ticket + x * 16u, 1u);
+                if (t < per_range) {
+                    t += x * per_range;
+                    break;
+                }
+                t = per_range;
+            }
+            s_tile = t;
+        }
     }
     smem[tid] = tid;                      // touch the dynamic LDS so that the allocation is real
     __syncthreads();
     const unsigned tile = s_tile;
+    const bool chain_head = per_range ? (tile % per_range) == 0 : tile == 0;      // starts from a known base
     spin_work(pre);
     if (tid < 16 && do_lookback) {
         const unsigned value = tile * 16u + tid + 1u;
-        __hip_atomic_store((gu64*)status + (unsigned long long)tile * 16 + tid, ((unsigned long long)(epoch * 4u + (tile == 0 ? kInc : kAgg)) << 32) | value,
+        __hip_atomic_store((gu64*)status + (unsigned long long)tile * 16 + tid, ((unsigned long long)(epoch * 4u + (chain_head ? kInc : kAgg)) << 32) | value,
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned sum = 0, depth = 0, spins = 0;
-        bool done = tile == 0;
+        bool done = chain_head;
         long long j = (long long)tile - 1;
         while (!done) {
             unsigned long long x[WINDOW];
@@ -82,7 +103,7 @@ __global__ __launch_bounds__(256) void lookback_kernel(unsigned long long* statu
                 break;
             }
         }
-        if (tile != 0) {
+        if (!chain_head) {
             __hip_atomic_store((gu64*)status + (unsigned long long)tile * 16 + tid, ((unsigned long long)(epoch * 4u + kInc) << 32) | (sum + value),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -98,6 +119,7 @@ __global__ __launch_bounds__(256) void lookback_kernel(unsigned long long* statu
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 static int g_lds_bytes = 27 * 1024;
+static unsigned g_per_xcd = 0;
 
 template <int WINDOW>
 int run(unsigned ntiles, int pre, int post, unsigned long long* status, unsigned* ticket, unsigned* excl, unsigned long long* depth, unsigned* timeout, unsigned& epoch)
@@ -110,10 +132,11 @@ int run(unsigned ntiles, int pre, int post, unsigned long long* status, unsigned
         unsigned long long dsum = 0;
         for (int rep = 0; rep < 3; ++rep) {
             ++epoch;
-            CK(hipMemset(ticket, 0, 4));
+            CK(hipMemset(ticket, 0, 8 * 64));
             CK(hipMemset(depth, 0, 8));
             CK(hipEventRecord(a));
-            hipLaunchKernelGGL(lookback_kernel<WINDOW>, dim3(ntiles), dim3(256), g_lds_bytes, 0, status, ticket, epoch, excl, depth, pre, post, lb, timeout);
+            hipLaunchKernelGGL(lookback_kernel<WINDOW>, dim3(ntiles), dim3(256), g_lds_bytes, 0, status, ticket, epoch, excl, depth, pre, post, lb, timeout,
+                               g_per_xcd ? ntiles / 8 : 0u);
             CK(hipEventRecord(b));
             CK(hipEventSynchronize(b));
             float ms = 0;
@@ -129,6 +152,7 @@ int run(unsigned ntiles, int pre, int post, unsigned long long* status, unsigned
             CK(hipMemcpy(h.data(), excl, h.size() * 4, hipMemcpyDeviceToHost));
             std::vector<unsigned> run16(16, 0);
             for (unsigned t = 0; t < ntiles && ok; ++t) {
+                if (g_per_xcd && t % (ntiles / 8) == 0) run16.assign(16, 0);      // every range's chain starts from its own base
                 for (unsigned d = 0; d < 16; ++d) {
                     ok = ok && h[static_cast<size_t>(t) * 16 + d] == run16[d];
                     run16[d] += t * 16u + d + 1u;
@@ -145,12 +169,15 @@ int main(int argc, char** argv)
 {
     const unsigned ntiles = argc > 1 ? std::strtoul(argv[1], nullptr, 10) : 65536;
     if (argc > 2) g_lds_bytes = std::atoi(argv[2]) * 1024;     // e.g. 108: one workgroup per CU, a 16k-key "supertile" of four 4k tiles
+    if (argc > 3) g_per_xcd = std::atoi(argv[3]) != 0;         // eight chains, one per XCD (ntiles must be a multiple of 8)
+    if (g_per_xcd && ntiles % 8) return 2;
+    std::printf("%s\n", g_per_xcd ? "EIGHT chains: one ticket word and one contiguous tile range per XCD (HW_REG_XCC_ID)" : "ONE chain over all tiles");
     unsigned long long *status, *depth;
     unsigned *ticket, *excl, *timeout;
     CK(hipMalloc(&status, static_cast<size_t>(ntiles) * 16 * 8));
     CK(hipMemset(status, 0, static_cast<size_t>(ntiles) * 16 * 8));
     CK(hipMalloc(&depth, 8));
-    CK(hipMalloc(&ticket, 4));
+    CK(hipMalloc(&ticket, 8 * 64));
     CK(hipMalloc(&excl, static_cast<size_t>(ntiles) * 16 * 4));
     CK(hipMalloc(&timeout, 4));
     CK(hipMemset(timeout, 0, 4));
