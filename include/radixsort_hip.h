@@ -87,6 +87,12 @@ typedef enum rsx_option {
                                  launches instead of 2 passes + 1.  Same table, same result; not taken while RSX_OPT_PROFILE is 1, with
                                  RSX_OPT_GRAPH, or beyond RSX_OPT_FUSED_SCAN_MAX_GROUPS (the same co-residency rule). */
     RSX_OPT_INLINE_SCAN_MAX_GROUPS = 18, /* (default 64 = 2^26 keys) largest table, in scan groups, that takes the inline scan */
+    RSX_OPT_REORDER8_KERNEL = 19, /* which scatter kernel the 8-bit passes use — same result, measured alternatives kept selectable (profiles/r03_tuning_log.md §1):
+                                 1 (default) two ranking rounds of the 4-bit machinery, the tile staged twice; 2 the same ranking with keys and
+                                 payload making ONE trip through LDS (better on Range, worse elsewhere); 3 ranks from one returning LDS atomic per
+                                 key on per-wave counters (fewest instructions, but LDS atomics under bank conflicts make it 1.6x slower on random
+                                 keys; faster on constant data); 3 relies on LDS atomics serving lanes in ascending lane order, probed on the
+                                 device at first use — where the probe fails kernel 1 runs instead. */
     RSX_OPT_DEBUG_RAISE_SCAN_TIMEOUT = 16, /* tests only: enqueue the store a timed-out fused scan makes (see rsx_check_status) */
     RSX_OPT_RADIX_BITS = 10,  /* digit width of the rsx_sort chain: 4 (default, the reference's _NUM_BITS_PER_RADIX, src/Parameters.h:25) or 8.
                                  With 8 a pass sorts by a whole byte (two stable 4-bit rounds inside LDS, one scatter of up to

@@ -195,7 +195,8 @@ struct rsx_engine {
     int small_scan = 1;         // rsx_sort: one-workgroup scan+paste for tables of <= 1024 tiles (env RSX_SMALL_SCAN)
     uint64_t radix8_min_keys = 1u << 19;        // 8-bit passes only above this many keys (env RSX_RADIX8_MIN_KEYS; at least one tile)
     int radix_bits = 4;         // RSX_OPT_RADIX_BITS: 4 (the reference's configuration) or 8 (half the passes; rsx_sort chain only)
-    int reorder8_version = 2;   // env RSX_REORDER8_V: 2 = keys make one trip through LDS (round 3), 1 = the two-trip kernel of round 2 (kept for A/B)
+    int reorder8_version = 1;   // env RSX_REORDER8_V / RSX_OPT_REORDER8_KERNEL: 3 = ranks from one returning LDS atomic per key (needs lds_atomics_ordered), 1 = two ranking rounds of the 4-bit machinery, 2 = its one-trip variant
+    int lds_atomics_ordered = -1;               // -1 not probed yet; 1: ds_add_rtn serves lanes in ascending lane order on this device (lds_atomic_order_probe_kernel); 0: it does not, kernel 3 is refused
     bool radix8_ready = false;                  // the five tables below exist and the reorder8 kernels may use their LDS
     uint32_t* counts8 = nullptr;                // 8-bit digits: raw counts [tile][256] (allocated on first use)
     uint32_t* table8 = nullptr;                 //   group-local exclusive prefixes [tile][256]
@@ -672,6 +673,25 @@ int ensure_radix8(rsx_engine* e)
             RSX_INITIALIZATION_FAILED);
     RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8v2_kernel<Key, kTileThreads, kKeysPerThread, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_v2p),
             RSX_INITIALIZATION_FAILED);
+    constexpr int lds_v3k = static_cast<int>(rsx::Reorder8V3Layout<Key, kTileThreads, kKeysPerThread, false>::BYTES);
+    constexpr int lds_v3p = static_cast<int>(rsx::Reorder8V3Layout<Key, kTileThreads, kKeysPerThread, true>::BYTES);
+    RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8v3_kernel<Key, kTileThreads, kKeysPerThread, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_v3k),
+            RSX_INITIALIZATION_FAILED);
+    RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8v3_kernel<Key, kTileThreads, kKeysPerThread, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_v3p),
+            RSX_INITIALIZATION_FAILED);
+    if (e->lds_atomics_ordered < 0) {
+        // kernel 3 ranks keys by the value a returning LDS atomic hands back and relies on lanes that meet on an address being served in
+        // ascending lane order: checked once per engine on the device it runs on (64 rounds of 16 instructions, patterns from all-equal
+        // to all-distinct); if it ever fails the engine keeps the two-round kernel
+        RSX_TRY(hipMemsetAsync(e->temp + 8, 0, 4, e->stream), RSX_INITIALIZATION_FAILED);
+        hipLaunchKernelGGL(rsx::lds_atomic_order_probe_kernel, dim3(1), dim3(256), 0, e->stream, e->temp + 8);
+        RSX_TRY(hipGetLastError(), RSX_INITIALIZATION_FAILED);
+        uint32_t bad = 1;
+        RSX_TRY(hipMemcpyAsync(&bad, e->temp + 8, 4, hipMemcpyDeviceToHost, e->stream), RSX_INITIALIZATION_FAILED);
+        RSX_TRY(hipStreamSynchronize(e->stream), RSX_INITIALIZATION_FAILED);
+        e->lds_atomics_ordered = bad == 0 ? 1 : 0;
+        if (bad) std::fprintf(stderr, "[radixsort_hip] LDS atomics do not return ranks in lane order on this device (%u mismatches): the 8-bit scatter keeps the two-round kernel\n", bad);
+    }
     e->radix8_ready = true;
     return RSX_OK;
 }
@@ -720,7 +740,19 @@ int sort8_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext
             Bracket b(e, PH_REORDER);
             constexpr size_t lds_v2k = rsx::Reorder8V2Layout<Key, kTileThreads, kKeysPerThread, false>::BYTES;
             constexpr size_t lds_v2p = rsx::Reorder8V2Layout<Key, kTileThreads, kKeysPerThread, true>::BYTES;
-            if (e->reorder8_version == 2) {
+            constexpr size_t lds_v3k = rsx::Reorder8V3Layout<Key, kTileThreads, kKeysPerThread, false>::BYTES;
+            constexpr size_t lds_v3p = rsx::Reorder8V3Layout<Key, kTileThreads, kKeysPerThread, true>::BYTES;
+            if (e->reorder8_version == 3 && e->lds_atomics_ordered == 1) {
+                if (e->has_payload) {
+                    hipLaunchKernelGGL((rsx::reorder8v3_kernel<Key, kTileThreads, kKeysPerThread, true>), dim3(g.blocks), dim3(kTileThreads), lds_v3p, e->stream,
+                                       static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->table8, e->gsum8, e->cbase8, chunk_groups,
+                                       count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip);
+                } else {
+                    hipLaunchKernelGGL((rsx::reorder8v3_kernel<Key, kTileThreads, kKeysPerThread, false>), dim3(g.blocks), dim3(kTileThreads), lds_v3k, e->stream,
+                                       static_cast<const Key*>(in), static_cast<Key*>(out), nullptr, nullptr, e->table8, e->gsum8, e->cbase8, chunk_groups,
+                                       count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip);
+                }
+            } else if (e->reorder8_version == 2) {
                 if (e->has_payload) {
                     hipLaunchKernelGGL((rsx::reorder8v2_kernel<Key, kTileThreads, kKeysPerThread, true>), dim3(g.blocks), dim3(kTileThreads),
                                        lds_v2p, e->stream,
@@ -1228,7 +1260,7 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
     if (const char* env = std::getenv("RSX_SMALL_TILE_MAX_KEYS")) e->small_tile_max_keys = std::min<uint64_t>(std::strtoull(env, nullptr, 10), static_cast<uint64_t>(rsx::kSelfScanMaxTiles) * kTileThreads * kSmallKeysPerThread);
     if (const char* env = std::getenv("RSX_SELF_SCAN_MAX")) e->self_scan_max = std::min<uint32_t>(static_cast<uint32_t>(std::atoi(env)), rsx::kSelfScanMaxTiles);
     if (const char* env = std::getenv("RSX_RADIX_BITS")) e->radix_bits = std::atoi(env) == 8 ? 8 : 4;
-    if (const char* env = std::getenv("RSX_REORDER8_V")) e->reorder8_version = std::atoi(env) == 1 ? 1 : 2;
+    if (const char* env = std::getenv("RSX_REORDER8_V")) e->reorder8_version = std::max(1, std::min(3, std::atoi(env)));
     if (const char* env = std::getenv("RSX_RADIX8_MIN_KEYS")) e->radix8_min_keys = std::max<uint64_t>(std::strtoull(env, nullptr, 10), kTileKeys);
     if (const char* env = std::getenv("RSX_PASTE_SCAN")) e->paste_scan = std::atoi(env) != 0;
     if (const char* env = std::getenv("RSX_FUSED_SCAN")) e->fused_scan = std::atoi(env) != 0;
@@ -1462,6 +1494,10 @@ int rsx_set_option(rsx_engine* e, int option, int64_t value)
     case RSX_OPT_SMALL_SCAN: e->small_scan = value != 0; return RSX_OK;
     case RSX_OPT_TILE_SORT: e->tile_sort = value != 0; return RSX_OK;
     case RSX_OPT_FUSED_SCAN: e->fused_scan = value != 0; return RSX_OK;
+    case RSX_OPT_REORDER8_KERNEL:
+        if (value < 1 || value > 3) return fail(RSX_CALCULATION_FAILED, "rsx_set_option: the 8-bit scatter kernel is 1, 2 or 3");
+        e->reorder8_version = static_cast<int>(value);
+        return RSX_OK;
     case RSX_OPT_INLINE_SCAN: e->inline_scan = value != 0; return RSX_OK;
     case RSX_OPT_INLINE_SCAN_MAX_GROUPS:
         if (value < 0) return fail(RSX_CALCULATION_FAILED, "rsx_set_option: negative group count");

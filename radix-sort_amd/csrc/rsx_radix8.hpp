@@ -758,4 +758,292 @@ __global__ __launch_bounds__(THREADS, (Reorder8V2Layout<Key, THREADS, KPT, PAYLO
     }
 }
 
+// ---------------------------------------------------------------------------
+// reorder8 v3 (round 3): ranks from ONE returning LDS atomic per key
+// ---------------------------------------------------------------------------
+// The two kernels above rank by the 4-bit machinery twice and are issue-bound (737 VALU per wave of 1,024 keys, vector ALUs busy
+// 78 % of a launch; profiles/r03_tuning_log.md §1).  Here a wave holds its 1,024 consecutive keys STRIPED — instruction i of lane l
+// is key i*64 + l — and every key takes one `ds_add_rtn_u32` on its wave's own 256 counters: LDS operations of a wave execute in
+// issue order, and lanes of one instruction that meet on an address are served in ascending lane order, so the returned value is
+// the key's rank among the wave's earlier keys of the same digit in INDEX order — a stable rank for ≈ 2 VALU.  (The lane order is
+// measured behaviour of this hardware, not an architectural promise: rsx_create's first use of the 8-bit path runs
+// lds_atomic_order_probe_kernel and the engine falls back to the two-round kernel if it ever fails; the stable-argsort tests run
+// on this kernel.)  A block scan over the 4 x 256 counts in (digit, wave) order turns counts into bases; slot = base + rank; keys and
+// payload make one trip through the padded image and leave as runs.  5 barriers, ≈ 300 VALU per wave.
+// A wave whose 64 keys of an instruction all share the digit (constant / long-run data) would serialise 64 lanes on one address:
+// instruction 0 stands for the wave as in reorder_kernel's look-ahead — only where it is uniform is every instruction tested and a
+// uniform one handled by lane 0 alone (+64, rank = returned value + lane).
+template <typename Key, int THREADS, int KPT, bool PAYLOAD>
+struct Reorder8V3Layout {
+    static constexpr int TILE = THREADS * KPT;
+    static constexpr int KD = sizeof(Key) / 4;
+    static constexpr int PADSH = (KD == 1) ? 5 : 4;
+    static constexpr int WAVES = THREADS / kWave;
+    static constexpr int XBUF_DW = (TILE + (TILE >> PADSH)) * KD;
+    static constexpr int PBUF_DW = PAYLOAD ? TILE + (TILE >> 5) : 0;
+    static constexpr int IMAGE_DW = XBUF_DW + PBUF_DW;
+    static constexpr int CNT_DW = WAVES * kRadix8;                       // [wave][digit]; dead before the image is written: shares its LDS
+    static constexpr int BODY_DW = IMAGE_DW > CNT_DW ? IMAGE_DW : CNT_DW;
+    static constexpr int TOTAL_DW = BODY_DW + 16 + kRadix8;              // + wave totals + run bases
+    static constexpr size_t BYTES = static_cast<size_t>(TOTAL_DW) * 4;
+    static constexpr int WGS_PER_CU = static_cast<int>((160 * 1024) / BYTES);
+    static constexpr int MIN_WAVES = (WGS_PER_CU * THREADS / 256) > RSX_REORDER8_WAVES_CAP ? RSX_REORDER8_WAVES_CAP : (WGS_PER_CU * THREADS / 256);
+    static_assert(THREADS == kRadix8 && KPT * kWave * WAVES == TILE, "one thread per digit scans the counts; a wave's keys are KPT rows of 64");
+};
+
+__device__ __forceinline__ uint32_t lds_add_rtn(uint32_t* p, uint32_t v)
+{
+    return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Does `ds_add_rtn_u32` hand lanes that meet on one address their old values in ascending lane order, and do a wave's LDS atomics
+// execute in issue order?  out[0] = number of (instruction, lane) pairs whose returned rank differs from the rank computed with
+// ballots; one workgroup of 256 threads, 64 rounds of 16 instructions with digit patterns from all-equal to all-distinct.
+__global__ __launch_bounds__(256) void lds_atomic_order_probe_kernel(uint32_t* out)
+{
+    __shared__ uint32_t cnt[4][kRadix8];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t bad = 0;
+    for (uint32_t round = 0; round < 64; ++round) {
+        for (uint32_t c = tid; c < 4 * kRadix8; c += 256) {
+            (&cnt[0][0])[c] = 0;
+        }
+        __syncthreads();
+        const uint32_t spread = 1u + (round * 37u) % 255u;          // number of distinct digits in play
+        uint32_t got[16], dig[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            uint32_t h = (tid * 2654435761u) ^ (round * 40503u) ^ (static_cast<uint32_t>(i) * 97u);
+            h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+            dig[i] = h % spread;
+            got[i] = lds_add_rtn(&cnt[wave][dig[i]], 1u);
+        }
+        // reference ranks without atomics: per instruction, the count the earlier instructions left in a second table + the lower lanes
+        // of this instruction with the same digit (ballots over the digit's 8 bits); the highest lane of each group writes the new count
+        __syncthreads();
+        __shared__ uint32_t ref[4][kRadix8];
+        for (uint32_t c = tid; c < 4 * kRadix8; c += 256) {
+            (&ref[0][0])[c] = 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t before = ref[wave][dig[i]];               // all lanes read the count left by instructions 0..i-1
+            __builtin_amdgcn_wave_barrier();
+            unsigned long long same = ~0ull;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const bool bit = (dig[i] >> b) & 1u;
+                const unsigned long long vote = __ballot(bit);
+                same &= bit ? vote : ~vote;
+            }
+            const uint32_t lower = static_cast<uint32_t>(__popcll(same & ((1ull << lane) - 1ull)));
+            if (before + lower != got[i]) {
+                ++bad;
+            }
+            const bool leader = (same >> lane) == 1ull;
+            if (leader) {
+                ref[wave][dig[i]] = before + static_cast<uint32_t>(__popcll(same));
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+    }
+    if (bad) {
+        atomicAdd(out, bad);
+    }
+}
+
+template <typename Key, int THREADS, int KPT, bool PAYLOAD>
+__global__ __launch_bounds__(THREADS, (Reorder8V3Layout<Key, THREADS, KPT, PAYLOAD>::MIN_WAVES)) void reorder8v3_kernel(
+    const Key* __restrict__ in, Key* __restrict__ out, const uint32_t* __restrict__ pin, uint32_t* __restrict__ pout,
+    const uint32_t* __restrict__ table8, const uint32_t* __restrict__ gsum8, const uint32_t* __restrict__ cbase8,
+    uint32_t chunk_groups, uint64_t n, uint32_t ntiles, uint32_t tiles_per_xcd, int remap, int shift, Key flip)
+{
+    using L = Reorder8V3Layout<Key, THREADS, KPT, PAYLOAD>;
+    constexpr int TILE = L::TILE;
+    constexpr uint32_t PBUF_BYTES = L::XBUF_DW * 4;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t* cnt = smem;                         // [wave][digit] counts, then bases
+    uint32_t* wtot = smem + L::BODY_DW;
+    uint32_t* gb = wtot + 16;                     // per digit: (global slot of the tile's first key with it) - (its tile-local slot)
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    const uint32_t tile = tile_of_block(blockIdx.x, tiles_per_xcd, remap & ~2);
+    if (tile >= ntiles) {
+        return;
+    }
+    if (!lds_base_is_zero(smem)) {
+        __builtin_trap();           // lds_store_at addresses the image from LDS address 0
+    }
+    const uint64_t base = static_cast<uint64_t>(tile) * TILE;
+    const uint64_t left = n - base;
+    const uint32_t valid = left < static_cast<uint64_t>(TILE) ? static_cast<uint32_t>(left) : static_cast<uint32_t>(TILE);
+    const bool full = (valid == TILE);
+    const Key pad_key = static_cast<Key>(~Key{0});        // digit 255, behind every real key of the tile (keys are held sign-flipped)
+    const bool hi = sizeof(Key) == 8 && shift >= 32;
+    const uint32_t sh = static_cast<uint32_t>(shift) & 31u;
+
+    const uint32_t group = tile / kScan8Tiles;
+    const uint32_t my_base = table8[static_cast<uint64_t>(tile) * kRadix8 + tid] + gsum8[static_cast<uint64_t>(group) * kRadix8 + tid] +
+                             cbase8[static_cast<uint64_t>(group / chunk_groups) * kRadix8 + tid];
+
+    // striped: element i of this thread is key wave*1024 + i*64 + lane of the tile (a wave-instruction reads 64 consecutive keys)
+    const uint32_t first_li = wave * (KPT * kWave) + lane;
+    Key k[KPT];
+    uint32_t pl[PAYLOAD ? KPT : 1];
+    if (full) {
+        const Key* src = in + base + first_li;
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            k[i] = src[i * kWave];
+        }
+        if constexpr (PAYLOAD) {
+            const uint32_t* psrc = pin + base + first_li;
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                pl[i] = psrc[i * kWave];
+            }
+        }
+        if (flip != Key{0}) {
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                k[i] ^= flip;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const uint32_t li = first_li + static_cast<uint32_t>(i) * kWave;
+            k[i] = li < valid ? static_cast<Key>(in[base + li] ^ flip) : pad_key;
+            if constexpr (PAYLOAD) {
+                pl[i] = li < valid ? pin[base + li] : 0u;
+            }
+        }
+    }
+    gb[tid] = my_base;           // (read after several barriers)
+#pragma unroll
+    for (int q = 0; q < L::WAVES; ++q) {
+        cnt[q * kRadix8 + tid] = 0;
+    }
+    __syncthreads();
+    // ---- ranks: one returning LDS atomic per key on the wave's own counters -------------------------------------------------------
+    uint32_t* wcnt = cnt + wave * kRadix8;
+    uint32_t slot[KPT];          // first the rank inside (wave, digit), then the tile-local slot
+    {
+        const uint32_t d0 = __builtin_amdgcn_ubfe(field_word(k[0], hi), sh, 8u);
+        if (__builtin_expect(__ballot(d0 != static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(d0)))) != 0ull, 1)) {
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                slot[i] = lds_add_rtn(wcnt + __builtin_amdgcn_ubfe(field_word(k[i], hi), sh, 8u), 1u);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                const uint32_t d = __builtin_amdgcn_ubfe(field_word(k[i], hi), sh, 8u);
+                const uint32_t first = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(d)));
+                if (__ballot(d != first) == 0ull) {
+                    uint32_t old = 0;
+                    if (lane == 0) {
+                        old = lds_add_rtn(wcnt + first, static_cast<uint32_t>(kWave));
+                    }
+                    slot[i] = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(old))) + lane;
+                } else {
+                    slot[i] = lds_add_rtn(wcnt + d, 1u);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- counts -> bases in (digit, wave) order: thread d owns digit d ----------------------------------------------------------
+    {
+        uint32_t c[L::WAVES];
+        uint32_t tot = 0;
+#pragma unroll
+        for (int q = 0; q < L::WAVES; ++q) {
+            c[q] = cnt[q * kRadix8 + tid];
+            tot += c[q];
+        }
+        uint32_t all;
+        uint32_t run = block_exclusive_scan<THREADS, false>(tot, wtot, all);      // keys of the tile with a smaller digit
+#pragma unroll
+        for (int q = 0; q < L::WAVES; ++q) {
+            cnt[q * kRadix8 + tid] = run;
+            run += c[q];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        slot[i] += wcnt[__builtin_amdgcn_ubfe(field_word(k[i], hi), sh, 8u)];
+    }
+    __syncthreads();                 // the image overlays the counters: nobody may still be reading them
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        lds_store_at<Key>(add_lshl<(sizeof(Key) == 4 ? 2 : 3)>(slot[i], slot[i] >> L::PADSH), k[i]);
+    }
+    if constexpr (PAYLOAD) {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            lds_store_at<uint32_t>(PBUF_BYTES + add_lshl<2>(slot[i], slot[i] >> 5), pl[i]);
+        }
+    }
+    __syncthreads();
+    // leave as runs: slot i = r*THREADS + tid, its global slot = gb[digit] + i
+    constexpr uint32_t RSTRIDE = THREADS + (THREADS >> L::PADSH);
+    const uint32_t rd_base = tid + (tid >> L::PADSH);
+    const Key* xk = reinterpret_cast<const Key*>(smem);
+    Key okey[KPT];
+#pragma unroll
+    for (int r = 0; r < KPT; ++r) {
+        okey[r] = xk[rd_base + static_cast<uint32_t>(r) * RSTRIDE];
+    }
+    uint32_t pay[PAYLOAD ? KPT : 1];
+    if constexpr (PAYLOAD) {
+        constexpr uint32_t PSTRIDE = THREADS + (THREADS >> 5);
+        const uint32_t pd_base = L::XBUF_DW + tid + (tid >> 5);
+#pragma unroll
+        for (int r = 0; r < KPT; ++r) {
+            pay[r] = smem[pd_base + static_cast<uint32_t>(r) * PSTRIDE];
+        }
+    }
+    uint32_t g[KPT];
+#pragma unroll
+    for (int r = 0; r < KPT; ++r) {
+        g[r] = gb[__builtin_amdgcn_ubfe(field_word(okey[r], hi), sh, 8u)];
+    }
+#pragma unroll
+    for (int r = 0; r < KPT; ++r) {
+        g[r] += tid + static_cast<uint32_t>(r) * THREADS;
+    }
+    if (flip != Key{0}) {        // (uniform)
+#pragma unroll
+        for (int r = 0; r < KPT; ++r) {
+            okey[r] ^= flip;
+        }
+    }
+    if (full) {
+#pragma unroll
+        for (int r = 0; r < KPT; ++r) {
+            out[g[r]] = okey[r];
+        }
+        if constexpr (PAYLOAD) {
+#pragma unroll
+            for (int r = 0; r < KPT; ++r) {
+                pout[g[r]] = pay[r];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < KPT; ++r) {
+            if (static_cast<uint32_t>(r) * THREADS + tid < valid) {
+                out[g[r]] = okey[r];
+                if constexpr (PAYLOAD) {
+                    pout[g[r]] = pay[r];
+                }
+            }
+        }
+    }
+}
+
 }  // namespace rsx

@@ -44,6 +44,20 @@ constexpr uint32_t kLaDummy = 2 * kRadix * kRadix;   // one spare counter past t
 #ifndef RSX_EARLY_RANK
 #define RSX_EARLY_RANK 1
 #endif
+// RSX_STREAM_STORES=1 (experiment, tuning log r03 §6): the scatter's key / payload stores carry the non-temporal hint — the output of a
+// pass is read again only after the whole pass, long after it has left every cache.
+#ifndef RSX_STREAM_STORES
+#define RSX_STREAM_STORES 0
+#endif
+template <typename T>
+__device__ __forceinline__ void scatter_store(T* p, T v)
+{
+#if RSX_STREAM_STORES
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
 #ifndef RSX_SCAN_TRAILING_BARRIER
 #define RSX_SCAN_TRAILING_BARRIER 0      // round 3: the raking scan's block scan ends without its own barrier (one barrier fewer per tile)
 #endif
@@ -689,7 +703,7 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
     } else if (full) {
 #pragma unroll
         for (int r = 0; r < KPT; ++r) {
-            out[g[r]] = okey[r];
+            scatter_store(&out[g[r]], okey[r]);
         }
     } else {
 #pragma unroll
@@ -747,7 +761,7 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
                         continue;
                     }
                 }
-                pout[g[r]] = pay[r];
+                scatter_store(&pout[g[r]], pay[r]);
             }
         }
     }

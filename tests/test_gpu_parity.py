@@ -1125,3 +1125,25 @@ def test_inline_scan_border_and_external_buffers(mod, oracle):
         assert np.array_equal(t.cpu().numpy().view(np.uint32), keys)
         low = keys & np.uint32((1 << 28) - 1)
         assert np.array_equal(outs[0][3:], keys[np.argsort(low, kind="stable")]) and np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("kernel", [1, 2, 3])
+@pytest.mark.parametrize("dt,n", [("uint32", 70001), ("int32", (1 << 20) + 4099), ("uint64", 300007), ("int64", 1 << 21)])
+def test_8bit_scatter_kernel_variants_are_stable_and_exact(mod, oracle, kernel, dt, n):
+    """RSX_OPT_REORDER8_KERNEL: the three 8-bit scatter kernels (two ranking rounds / one trip through LDS / ranks from returning LDS
+    atomics) give the same keys and the same STABLE payload order — ties everywhere (a third of the keys equal), ragged sizes, all
+    key types, and constant data (the wave-uniform path of kernel 3)."""
+    keys = oracle.dataset("SeededUniform", dt, n, seed=kernel + n % 13)
+    keys[::3] = keys[7]
+    for data in (keys, np.full(n, keys[11], dtype=dt)):
+        with mod.Engine(dt, n, payload=True) as e:
+            e.set_option(mod.OPT_RADIX_BITS, 8)
+            e.set_option(mod.OPT_REORDER8_KERNEL, kernel)
+            e.upload(data, np.arange(n, dtype=np.uint32))
+            e.sort()
+            ks, ps = e.download(want_perm=True)
+        assert np.array_equal(ks, np.sort(data))
+        assert np.array_equal(ps, np.argsort(data, kind="stable").astype(np.uint32))
+    with mod.Engine(dt, 4096) as e:
+        with pytest.raises(mod.RadixSortError):
+            e.set_option(mod.OPT_REORDER8_KERNEL, 4)

@@ -24,8 +24,8 @@ if has 2; then
 import csv, json
 line = json.load(open("$O/bench_under_rocprof.json"))
 rows = {r["Name"]: r for r in csv.DictReader(open("$O/kernel_stats.csv"))}
-fused = next(v for k, v in rows.items() if "reorder_kernel<unsigned int, 256, 16, false, true, false>" in k)
-plain = next(v for k, v in rows.items() if "reorder_kernel<unsigned int, 256, 16, false, false, false>" in k)
+fused = next(v for k, v in rows.items() if "reorder_kernel<unsigned int, 256, 16, false, true, false," in k)
+plain = next(v for k, v in rows.items() if "reorder_kernel<unsigned int, 256, 16, false, false, false," in k)
 fa, pa = float(fused["AverageNs"]) * 1e-6, float(plain["AverageNs"]) * 1e-6
 w = (7 * fa + pa) / 8
 open("$O/rocprof_vs_events.txt", "w").write(

@@ -42,6 +42,11 @@ for it in range(iters):
     e.set_option(m.OPT_XCD_PHASE, (-1, 0, int(rng.integers(1, 40)))[rng.integers(0, 3)])
     e.set_option(m.OPT_SMALL_TILE_MAX_KEYS, (1 << 19, 0, 1 << 20)[rng.integers(0, 3)])
     e.set_option(m.OPT_SELF_SCAN_MAX_TILES, (1024, 1024, 100)[rng.integers(0, 3)])
+    # round 3: the scan inside the reorder launch, the fused scan's group limit, the three 8-bit scatter kernels
+    e.set_option(m.OPT_INLINE_SCAN, int(rng.integers(0, 2)))
+    e.set_option(m.OPT_INLINE_SCAN_MAX_GROUPS, (64, 2, 512)[rng.integers(0, 3)])
+    e.set_option(m.OPT_FUSED_SCAN_MAX_GROUPS, (-1, 1, 0)[rng.integers(0, 3)])
+    e.set_option(m.OPT_REORDER8_KERNEL, int(rng.integers(1, 4)))
     perm = np.arange(n, dtype=np.uint32) if payload else None
     e.upload(keys, perm)
     e.sort()
@@ -50,6 +55,7 @@ for it in range(iters):
         ok = np.array_equal(ks, np.sort(keys, kind="stable")) and np.array_equal(ps, np.argsort(keys, kind="stable").astype(np.uint32))
     else:
         ok = np.array_equal(e.download(), np.sort(keys, kind="stable"))
+    e.sync()             # a fused / inline scan that timed out would be reported here
     if ok and it % 3 == 0:
         # the multi-GPU partitions on the same keys: sampled splitters, then the top bits
         import torch
