@@ -196,6 +196,13 @@ struct rsx_engine {
     uint64_t radix8_min_keys = 1u << 19;        // 8-bit passes only above this many keys (env RSX_RADIX8_MIN_KEYS; at least one tile)
     int radix_bits = 4;         // RSX_OPT_RADIX_BITS: 4 (the reference's configuration) or 8 (half the passes; rsx_sort chain only)
     int reorder8_version = 1;   // env RSX_REORDER8_V / RSX_OPT_REORDER8_KERNEL: 3 = ranks from one returning LDS atomic per key (needs lds_atomics_ordered), 1 = two ranking rounds of the 4-bit machinery, 2 = its one-trip variant
+    // Unused dynamic LDS per workgroup of the default 8-bit scatter = fewer workgroups per CU.  The 8-bit scatter leaves a tile as ~256 runs of ~16 keys whose first and last
+    // sectors are completed by the NEIGHBOURING tile's runs; the halves merge only while the line is still in the XCD's L2, and the lines held open grow with the tiles in
+    // flight: 64-bit elements (uint64 keys, or uint32 key + payload packed) overflow the 4 MiB at 3 workgroups per CU and are 10-27 % faster at 2
+    // (profiles/r03_8bit_workgroups_per_cu.txt, r03_ab8_workgroups_policy.txt).  -1 = that policy (r8_extra_lds_for); env RSX_R8_EXTRA_LDS_KB = a fixed value for every variant.
+    long r8_extra_lds = -1;
+    size_t reorder_extra_lds = 0;       // experiment (env RSX_REORDER_EXTRA_LDS_KB, <= 64): the same for the 4-bit reorder launches of full tiles (fewer workgroups per CU)
+    int r8_packed = 1;          // 8-bit scatter of uint32 keys WITH payload: key and payload as one 64-bit element through the ranking rounds (env RSX_R8_PACKED; kernel 1 only)
     int lds_atomics_ordered = -1;               // -1 not probed yet; 1: ds_add_rtn serves lanes in ascending lane order on this device (lds_atomic_order_probe_kernel); 0: it does not, kernel 3 is refused
     bool radix8_ready = false;                  // the five tables below exist and the reorder8 kernels may use their LDS
     uint32_t* counts8 = nullptr;                // 8-bit digits: raw counts [tile][256] (allocated on first use)
@@ -454,7 +461,7 @@ int launch_reorder_t(rsx_engine* e, const void* in, void* out, const uint32_t* p
     e->last_shift = shift;
     Bracket b(e, PH_REORDER);
     hipLaunchKernelGGL((rsx::reorder_kernel<Key, kTileThreads, KPT, PAYLOAD, LOOKAHEAD, RANGED>), dim3(g.blocks), dim3(kTileThreads),
-                       L::BYTES, e->stream, static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->table, count,
+                       L::BYTES + (KPT == kKeysPerThread ? e->reorder_extra_lds : 0), e->stream, static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->table, count,
                        g.ntiles, g.tiles_per_xcd, g.remap | ((e->reverse_odd && ((shift / RSX_RADIX_BITS) & 1)) ? 2 : 0), shift, flip_mask<Key>(e), mask,
                        next_counts ? next_counts : e->counts_next, next_shift,
 #ifdef RSX_STAMPS
@@ -486,7 +493,7 @@ int allow_lds()
 {
     using L = rsx::ReorderLayout<Key, kTileThreads, kKeysPerThread, (!RANGED && RSX_ALIAS_COUNTERS != 0)>;
     RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder_kernel<Key, kTileThreads, kKeysPerThread, PAYLOAD, LOOKAHEAD, RANGED>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L::BYTES)),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L::BYTES) + (64 << 10)),
             RSX_INITIALIZATION_FAILED);
     return RSX_OK;
 }
@@ -648,6 +655,18 @@ int sort_selfscan_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* e
 }
 
 #if RSX_TILE_THREADS == 256      // (the 8-bit kernels are written for 256-thread tiles: one thread per digit)
+// extra dynamic LDS of the default 8-bit scatter, by variant: 2 workgroups per CU instead of 3 for 64-bit elements (see rsx_engine::r8_extra_lds)
+size_t r8_extra_lds_for(const rsx_engine* e, bool elem64, bool separate_payload)
+{
+    if (e->r8_extra_lds >= 0) return static_cast<size_t>(e->r8_extra_lds);
+    // uint32 keys only: 29 KiB + 4 = four workgroups per CU instead of five — 1 % slower on random keys (0.586 -> 0.579 of peak), 4-8 % faster on Range / InvertedRange
+    // (0.55-0.57 -> 0.584-0.594; r03_8bit_range_workgroups_per_cu.txt); with a separate payload array (RSX_R8_PACKED=0) the registers allow four anyway
+    if (!elem64) return separate_payload ? 0 : (4u << 10);
+    // uint64 keys / packed uint32 key + payload: 45 KiB + 8 = two workgroups per CU (+10 % / +27 % on random keys, +15 % on Range).  uint64 keys with
+    // a payload array stay at three: two measured 0.58-0.59 against 0.55-0.62 on random keys and 9 % slower on constant data (r03_ab8_workgroups_policy.txt)
+    return separate_payload ? 0 : (8u << 10);
+}
+
 // The 8-bit chain's tables, allocated on first use — by sort_chain BEFORE any stream capture begins (an allocation inside
 // hipStreamBeginCapture invalidates the capture) and by rsx_set_option(RSX_OPT_RADIX_BITS, 8).  A call that failed half-way
 // keeps what it got and the next one asks for the rest.
@@ -656,6 +675,7 @@ int ensure_radix8(rsx_engine* e)
 {
     if (e->radix8_ready) return RSX_OK;
     using L = rsx::Reorder8Layout<Key, kTileThreads, kKeysPerThread>;
+    const int extra = e->r8_extra_lds >= 0 ? static_cast<int>(e->r8_extra_lds) : (16 << 10);      // the most any variant asks for
     const size_t rows = static_cast<size_t>(e->ntiles(e->capacity)) * rsx::kRadix8 * 4;
     const size_t groups = ((e->ntiles(e->capacity) + rsx::kScan8Tiles - 1) / rsx::kScan8Tiles) * rsx::kRadix8 * 4;
     if (!e->counts8) RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->counts8), rows), RSX_INITIALIZATION_FAILED);
@@ -664,15 +684,20 @@ int ensure_radix8(rsx_engine* e)
     if (!e->csum8) RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->csum8), rsx::kScan8MaxChunks * rsx::kRadix8 * 4), RSX_INITIALIZATION_FAILED);
     if (!e->cbase8) RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->cbase8), rsx::kScan8MaxChunks * rsx::kRadix8 * 4), RSX_INITIALIZATION_FAILED);
     RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L::BYTES)), RSX_INITIALIZATION_FAILED);
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L::BYTES) + extra), RSX_INITIALIZATION_FAILED);
     RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L::BYTES)), RSX_INITIALIZATION_FAILED);
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L::BYTES) + extra), RSX_INITIALIZATION_FAILED);
     constexpr int lds_v2k = static_cast<int>(rsx::Reorder8V2Layout<Key, kTileThreads, kKeysPerThread, false>::BYTES);
     constexpr int lds_v2p = static_cast<int>(rsx::Reorder8V2Layout<Key, kTileThreads, kKeysPerThread, true>::BYTES);
     RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8v2_kernel<Key, kTileThreads, kKeysPerThread, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_v2k),
             RSX_INITIALIZATION_FAILED);
     RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8v2_kernel<Key, kTileThreads, kKeysPerThread, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_v2p),
             RSX_INITIALIZATION_FAILED);
+    if constexpr (sizeof(Key) == 4) {
+        constexpr int lds_packed = static_cast<int>(rsx::Reorder8Layout<uint64_t, kTileThreads, kKeysPerThread>::BYTES);
+        RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8_kernel<uint64_t, kTileThreads, kKeysPerThread, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_packed + extra),
+                RSX_INITIALIZATION_FAILED);
+    }
     constexpr int lds_v3k = static_cast<int>(rsx::Reorder8V3Layout<Key, kTileThreads, kKeysPerThread, false>::BYTES);
     constexpr int lds_v3p = static_cast<int>(rsx::Reorder8V3Layout<Key, kTileThreads, kKeysPerThread, true>::BYTES);
     RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8v3_kernel<Key, kTileThreads, kKeysPerThread, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_v3k),
@@ -764,12 +789,18 @@ int sort8_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext
                                        static_cast<const Key*>(in), static_cast<Key*>(out), nullptr, nullptr, e->table8, e->gsum8, e->cbase8, chunk_groups,
                                        count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip);
                 }
+            } else if (sizeof(Key) == 4 && e->has_payload && e->r8_packed) {
+                // uint32 key + payload as one 64-bit element (rsx::reorder8_kernel<.., PACKED32>)
+                constexpr size_t lds_packed = rsx::Reorder8Layout<uint64_t, kTileThreads, kKeysPerThread>::BYTES;
+                hipLaunchKernelGGL((rsx::reorder8_kernel<uint64_t, kTileThreads, kKeysPerThread, false, true>), dim3(g.blocks), dim3(kTileThreads), lds_packed + r8_extra_lds_for(e, true, false), e->stream,
+                                   static_cast<const uint64_t*>(in), static_cast<uint64_t*>(out), pin, pout, e->table8, e->gsum8, e->cbase8, chunk_groups,
+                                   count, g.ntiles, g.tiles_per_xcd, g.remap, shift, static_cast<uint64_t>(flip));
             } else if (e->has_payload) {
-                hipLaunchKernelGGL((rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, true>), dim3(g.blocks), dim3(kTileThreads), L::BYTES, e->stream,
+                hipLaunchKernelGGL((rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, true>), dim3(g.blocks), dim3(kTileThreads), L::BYTES + r8_extra_lds_for(e, sizeof(Key) == 8, true), e->stream,
                                    static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->table8, e->gsum8, e->cbase8, chunk_groups,
                                    count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip);
             } else {
-                hipLaunchKernelGGL((rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, false>), dim3(g.blocks), dim3(kTileThreads), L::BYTES, e->stream,
+                hipLaunchKernelGGL((rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, false>), dim3(g.blocks), dim3(kTileThreads), L::BYTES + r8_extra_lds_for(e, sizeof(Key) == 8, false), e->stream,
                                    static_cast<const Key*>(in), static_cast<Key*>(out), nullptr, nullptr, e->table8, e->gsum8, e->cbase8, chunk_groups,
                                    count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip);
             }
@@ -1260,6 +1291,9 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
     if (const char* env = std::getenv("RSX_SMALL_TILE_MAX_KEYS")) e->small_tile_max_keys = std::min<uint64_t>(std::strtoull(env, nullptr, 10), static_cast<uint64_t>(rsx::kSelfScanMaxTiles) * kTileThreads * kSmallKeysPerThread);
     if (const char* env = std::getenv("RSX_SELF_SCAN_MAX")) e->self_scan_max = std::min<uint32_t>(static_cast<uint32_t>(std::atoi(env)), rsx::kSelfScanMaxTiles);
     if (const char* env = std::getenv("RSX_RADIX_BITS")) e->radix_bits = std::atoi(env) == 8 ? 8 : 4;
+    if (const char* env = std::getenv("RSX_REORDER_EXTRA_LDS_KB")) e->reorder_extra_lds = static_cast<size_t>(std::max(0, std::min(64, std::atoi(env)))) << 10;
+    if (const char* env = std::getenv("RSX_R8_PACKED")) e->r8_packed = std::atoi(env) != 0;
+    if (const char* env = std::getenv("RSX_R8_EXTRA_LDS_KB")) e->r8_extra_lds = std::atoi(env) < 0 ? -1L : static_cast<long>(std::min(96, std::atoi(env))) * 1024;
     if (const char* env = std::getenv("RSX_REORDER8_V")) e->reorder8_version = std::max(1, std::min(3, std::atoi(env)));
     if (const char* env = std::getenv("RSX_RADIX8_MIN_KEYS")) e->radix8_min_keys = std::max<uint64_t>(std::strtoull(env, nullptr, 10), kTileKeys);
     if (const char* env = std::getenv("RSX_PASTE_SCAN")) e->paste_scan = std::atoi(env) != 0;

@@ -216,13 +216,18 @@ struct Reorder8Layout {
     static_assert(KPT == 16 && THREADS == kRadix8, "row geometry; one thread per digit handles the tile's table row");
 };
 
-template <typename Key, int THREADS, int KPT, bool PAYLOAD>
+// PACKED32 (uint32 keys WITH payload, instantiated as Key = uint64_t, PAYLOAD = false): key and payload travel through the two ranking
+// rounds as ONE 64-bit element (key in the low word, where the digit is taken; payload in the high word) — `in` / `out` really point at
+// uint32 keys, `pin` / `pout` at the payloads.  One 8-byte LDS access per element and round instead of two 4-byte ones, and none of the
+// payload's own trips (4 barriers fewer per tile): the uint32 + payload scatter then costs what the uint64 keys-only one costs.
+template <typename Key, int THREADS, int KPT, bool PAYLOAD, bool PACKED32 = false>
 __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREADS, KPT>::MIN_WAVES > 4 ? 4 : Reorder8Layout<Key, THREADS, KPT>::MIN_WAVES))) void reorder8_kernel(
     const Key* __restrict__ in, Key* __restrict__ out, const uint32_t* __restrict__ pin, uint32_t* __restrict__ pout,
     const uint32_t* __restrict__ table8, const uint32_t* __restrict__ gsum8, const uint32_t* __restrict__ cbase8,
     uint32_t chunk_groups, uint64_t n, uint32_t ntiles, uint32_t tiles_per_xcd, int remap, int shift, Key flip)
 {
     using L = Reorder8Layout<Key, THREADS, KPT>;
+    static_assert(!PACKED32 || (sizeof(Key) == 8 && !PAYLOAD), "packed (uint32 key, payload) elements are 64-bit and carry their payload themselves");
     constexpr int TILE = THREADS * KPT;
     constexpr int KD = L::KD;
     constexpr int VEC = KeyVec<Key>::N;
@@ -248,7 +253,7 @@ __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREAD
     // Inside the kernel keys are held with the sign bit flipped (k ^ flip: unsigned order = numeric order), so the
     // digits are plain bit fields; the flip is undone on the way out.  Unsigned types skip both (flip == 0, uniform).
     const Key pad_key = static_cast<Key>(~Key{0});        // digit 255, behind every real key of the tile
-    const bool hi = sizeof(Key) == 8 && shift >= 32;      // the byte never straddles the halves of a 64-bit key
+    const bool hi = !PACKED32 && sizeof(Key) == 8 && shift >= 32;      // the byte never straddles the halves of a 64-bit key
     const uint32_t sh = static_cast<uint32_t>(shift) & 31u;
 
     // this thread's digit of the tile's table row (latency hides under the key loads): global slot of the tile's first key with
@@ -259,7 +264,26 @@ __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREAD
 
     Key k[KPT];
     uint32_t pl[PAYLOAD ? KPT : 1];
-    if (full) {
+    if constexpr (PACKED32) {
+        const uint32_t* in32 = reinterpret_cast<const uint32_t*>(in);
+        if (full) {
+#pragma unroll
+            for (int q = 0; q < KPT / 4; ++q) {
+                const U32x4 a = *reinterpret_cast<const U32x4*>(in32 + base + tid * KPT + q * 4);
+                const U32x4 b = *reinterpret_cast<const U32x4*>(pin + base + tid * KPT + q * 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    k[q * 4 + c] = (static_cast<Key>(b.v[c]) << 32) | static_cast<Key>(a.v[c] ^ static_cast<uint32_t>(flip));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                const uint32_t li = tid * KPT + i;
+                k[i] = li < valid ? ((static_cast<Key>(pin[base + li]) << 32) | static_cast<Key>(in32[base + li] ^ static_cast<uint32_t>(flip))) : pad_key;
+            }
+        }
+    } else if (full) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const KeyVec<Key> v = load_keys16(in + base + tid * KPT + j * VEC);
@@ -417,7 +441,16 @@ __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREAD
                     okey[r] ^= flip;
                 }
             }
-            if (full) {
+            if constexpr (PACKED32) {
+                uint32_t* out32 = reinterpret_cast<uint32_t*>(out);
+#pragma unroll
+                for (int r = 0; r < KPT; ++r) {
+                    if (full || static_cast<uint32_t>(r) * THREADS + tid < valid) {
+                        out32[g[r]] = static_cast<uint32_t>(okey[r]);
+                        pout[g[r]] = static_cast<uint32_t>(okey[r] >> 32);
+                    }
+                }
+            } else if (full) {
 #pragma unroll
                 for (int r = 0; r < KPT; ++r) {
                     out[g[r]] = okey[r];

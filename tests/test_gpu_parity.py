@@ -1133,10 +1133,18 @@ def test_8bit_scatter_kernel_variants_are_stable_and_exact(mod, oracle, kernel, 
     """RSX_OPT_REORDER8_KERNEL: the three 8-bit scatter kernels (two ranking rounds / one trip through LDS / ranks from returning LDS
     atomics) give the same keys and the same STABLE payload order — ties everywhere (a third of the keys equal), ragged sizes, all
     key types, and constant data (the wave-uniform path of kernel 3)."""
+    import os
     keys = oracle.dataset("SeededUniform", dt, n, seed=kernel + n % 13)
     keys[::3] = keys[7]
-    for data in (keys, np.full(n, keys[11], dtype=dt)):
-        with mod.Engine(dt, n, payload=True) as e:
+    # (kernel 1 carries a uint32 key and its payload as ONE 64-bit element by default; RSX_R8_PACKED=0, read at rsx_create, keeps them apart)
+    cases = [(keys, "1"), (np.full(n, keys[11], dtype=dt), "1")] + ([(keys, "0")] if kernel == 1 and np.dtype(dt).itemsize == 4 else [])
+    for data, packed in cases:
+        os.environ["RSX_R8_PACKED"] = packed
+        try:
+            e = mod.Engine(dt, n, payload=True)
+        finally:
+            del os.environ["RSX_R8_PACKED"]
+        with e:
             e.set_option(mod.OPT_RADIX_BITS, 8)
             e.set_option(mod.OPT_REORDER8_KERNEL, kernel)
             e.upload(data, np.arange(n, dtype=np.uint32))
