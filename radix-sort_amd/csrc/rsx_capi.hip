@@ -662,9 +662,10 @@ size_t r8_extra_lds_for(const rsx_engine* e, bool elem64, bool separate_payload)
     // uint32 keys only: 29 KiB + 4 = four workgroups per CU instead of five — 1 % slower on random keys (0.586 -> 0.579 of peak), 4-8 % faster on Range / InvertedRange
     // (0.55-0.57 -> 0.584-0.594; r03_8bit_range_workgroups_per_cu.txt); with a separate payload array (RSX_R8_PACKED=0) the registers allow four anyway
     if (!elem64) return separate_payload ? 0 : (4u << 10);
-    // uint64 keys / packed uint32 key + payload: 45 KiB + 8 = two workgroups per CU (+10 % / +27 % on random keys, +15 % on Range).  uint64 keys with
-    // a payload array stay at three: two measured 0.58-0.59 against 0.55-0.62 on random keys and 9 % slower on constant data (r03_ab8_workgroups_policy.txt)
-    return separate_payload ? 0 : (8u << 10);
+    // uint64 keys / packed uint32 key + payload: 45 KiB + 8 = two workgroups per CU (+10 % / +27 % on random keys, +15 % on Range), and the spread between
+    // engines of one process — the "modes" of rounds 1-2 — shrinks from 7-11 % to 2 % (profiles/r03_modes_vs_workgroups_per_cu.txt).  uint64 keys with a payload
+    // array likewise (six engines: 14.9-16.6 ms per sort at three, 14.4-14.8 at two), at the price of 9 % on constant data, which has nothing to merge
+    return separate_payload ? (16u << 10) : (8u << 10);
 }
 
 // The 8-bit chain's tables, allocated on first use — by sort_chain BEFORE any stream capture begins (an allocation inside
