@@ -93,6 +93,9 @@ typedef enum rsx_option {
                                  key on per-wave counters (fewest instructions, but LDS atomics under bank conflicts make it 1.6x slower on random
                                  keys; faster on constant data); 3 relies on LDS atomics serving lanes in ascending lane order, probed on the
                                  device at first use — where the probe fails kernel 1 runs instead. */
+    RSX_OPT_REORDER8_STAY = 20, /* kernel 1 of the 8-bit passes as a grid that stays: N > 0 launches N workgroups per CU that walk the tiles (each XCD its
+                                 own range, neighbours in flight together) and load their next tile while they rank the current one; 0 = one
+                                 workgroup per tile; -1 (default) = the engine's per-variant policy.  At most 8. */
     RSX_OPT_DEBUG_RAISE_SCAN_TIMEOUT = 16, /* tests only: enqueue the store a timed-out fused scan makes (see rsx_check_status) */
     RSX_OPT_RADIX_BITS = 10,  /* digit width of the rsx_sort chain: 4 (default, the reference's _NUM_BITS_PER_RADIX, src/Parameters.h:25) or 8.
                                  With 8 a pass sorts by a whole byte (two stable 4-bit rounds inside LDS, one scatter of up to

@@ -30,7 +30,7 @@ STATUS_NAMES = [
     "PROGRAM_CREATION_FAILED", "NO_SOURCE_FOUND", "LOADING_SOURCE_FAILED",
 ]
 
-OPT_PROFILE, OPT_XCD_REMAP, OPT_FIRST_PASS, OPT_LAST_PASS, OPT_LOOKAHEAD, OPT_REF_DIAGNOSTICS, OPT_GRAPH, OPT_SMALL_SCAN, OPT_TILE_SORT, OPT_FUSED_SCAN, OPT_RADIX_BITS, OPT_SELF_SCAN, OPT_SMALL_TILE_MAX_KEYS, OPT_XCD_PHASE, OPT_SELF_SCAN_MAX_TILES, OPT_FUSED_SCAN_MAX_GROUPS, OPT_DEBUG_RAISE_SCAN_TIMEOUT, OPT_INLINE_SCAN, OPT_INLINE_SCAN_MAX_GROUPS, OPT_REORDER8_KERNEL = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19
+OPT_PROFILE, OPT_XCD_REMAP, OPT_FIRST_PASS, OPT_LAST_PASS, OPT_LOOKAHEAD, OPT_REF_DIAGNOSTICS, OPT_GRAPH, OPT_SMALL_SCAN, OPT_TILE_SORT, OPT_FUSED_SCAN, OPT_RADIX_BITS, OPT_SELF_SCAN, OPT_SMALL_TILE_MAX_KEYS, OPT_XCD_PHASE, OPT_SELF_SCAN_MAX_TILES, OPT_FUSED_SCAN_MAX_GROUPS, OPT_DEBUG_RAISE_SCAN_TIMEOUT, OPT_INLINE_SCAN, OPT_INLINE_SCAN_MAX_GROUPS, OPT_REORDER8_KERNEL, OPT_REORDER8_STAY = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20
 
 # every symbol include/radixsort_hip.h declares (tests/test_capi_symbols.py checks the header against this)
 SYMBOLS = [

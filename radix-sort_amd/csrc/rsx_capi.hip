@@ -201,7 +201,13 @@ struct rsx_engine {
     // flight: 64-bit elements (uint64 keys, or uint32 key + payload packed) overflow the 4 MiB at 3 workgroups per CU and are 10-27 % faster at 2
     // (profiles/r03_8bit_workgroups_per_cu.txt, r03_ab8_workgroups_policy.txt).  -1 = that policy (r8_extra_lds_for); env RSX_R8_EXTRA_LDS_KB = a fixed value for every variant.
     long r8_extra_lds = -1;
-    size_t reorder_extra_lds = 0;       // experiment (env RSX_REORDER_EXTRA_LDS_KB, <= 64): the same for the 4-bit reorder launches of full tiles (fewer workgroups per CU)
+    // the same for the 4-bit reorder launches of 4096-key tiles (env RSX_REORDER_EXTRA_LDS_KB, <= 64; -1 = policy): only uint32 keys WITH a payload gain from
+    // fewer workgroups per CU (three instead of four: six engines 6.26-6.84 -> 6.17-6.55 ms per sort); uint32 keys, uint64 keys and uint64 + payload lose 1-20 %
+    // (profiles/r03_4bit_workgroups_per_cu.txt, r03_modes_u32pay4_workgroups_per_cu.txt)
+    long reorder_extra_lds = -1;
+    // default 8-bit scatter as a grid that stays (rsx::reorder8_stay_kernel): workgroups per CU of that grid, 0 = one workgroup per tile (env RSX_R8_STAY; -1 = policy)
+    int r8_stay = -1;
+    int num_cus = 0;
     int r8_packed = 1;          // 8-bit scatter of uint32 keys WITH payload: key and payload as one 64-bit element through the ranking rounds (env RSX_R8_PACKED; kernel 1 only)
     int lds_atomics_ordered = -1;               // -1 not probed yet; 1: ds_add_rtn serves lanes in ascending lane order on this device (lds_atomic_order_probe_kernel); 0: it does not, kernel 3 is refused
     bool radix8_ready = false;                  // the five tables below exist and the reorder8 kernels may use their LDS
@@ -461,7 +467,8 @@ int launch_reorder_t(rsx_engine* e, const void* in, void* out, const uint32_t* p
     e->last_shift = shift;
     Bracket b(e, PH_REORDER);
     hipLaunchKernelGGL((rsx::reorder_kernel<Key, kTileThreads, KPT, PAYLOAD, LOOKAHEAD, RANGED>), dim3(g.blocks), dim3(kTileThreads),
-                       L::BYTES + (KPT == kKeysPerThread ? e->reorder_extra_lds : 0), e->stream, static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->table, count,
+                       L::BYTES + (KPT != kKeysPerThread ? 0u : e->reorder_extra_lds >= 0 ? static_cast<size_t>(e->reorder_extra_lds) : (PAYLOAD && sizeof(Key) == 4 && !RANGED) ? (16u << 10) : 0u),
+                       e->stream, static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->table, count,
                        g.ntiles, g.tiles_per_xcd, g.remap | ((e->reverse_odd && ((shift / RSX_RADIX_BITS) & 1)) ? 2 : 0), shift, flip_mask<Key>(e), mask,
                        next_counts ? next_counts : e->counts_next, next_shift,
 #ifdef RSX_STAMPS
@@ -668,6 +675,14 @@ size_t r8_extra_lds_for(const rsx_engine* e, bool elem64, bool separate_payload)
     return separate_payload ? (16u << 10) : (8u << 10);
 }
 
+// workgroups per CU of the staying grid of the default 8-bit scatter (0 = one workgroup per tile), by variant
+int r8_stay_for(const rsx_engine* e, bool elem64, bool separate_payload)
+{
+    if (e->r8_stay >= 0) return e->r8_stay;
+    (void)elem64; (void)separate_payload;
+    return 0;
+}
+
 // The 8-bit chain's tables, allocated on first use — by sort_chain BEFORE any stream capture begins (an allocation inside
 // hipStreamBeginCapture invalidates the capture) and by rsx_set_option(RSX_OPT_RADIX_BITS, 8).  A call that failed half-way
 // keeps what it got and the next one asks for the rest.
@@ -688,6 +703,10 @@ int ensure_radix8(rsx_engine* e)
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L::BYTES) + extra), RSX_INITIALIZATION_FAILED);
     RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L::BYTES) + extra), RSX_INITIALIZATION_FAILED);
+    RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8_stay_kernel<Key, kTileThreads, kKeysPerThread, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L::BYTES) + extra), RSX_INITIALIZATION_FAILED);
+    RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8_stay_kernel<Key, kTileThreads, kKeysPerThread, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L::BYTES) + extra), RSX_INITIALIZATION_FAILED);
     constexpr int lds_v2k = static_cast<int>(rsx::Reorder8V2Layout<Key, kTileThreads, kKeysPerThread, false>::BYTES);
     constexpr int lds_v2p = static_cast<int>(rsx::Reorder8V2Layout<Key, kTileThreads, kKeysPerThread, true>::BYTES);
     RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8v2_kernel<Key, kTileThreads, kKeysPerThread, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_v2k),
@@ -697,6 +716,8 @@ int ensure_radix8(rsx_engine* e)
     if constexpr (sizeof(Key) == 4) {
         constexpr int lds_packed = static_cast<int>(rsx::Reorder8Layout<uint64_t, kTileThreads, kKeysPerThread>::BYTES);
         RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8_kernel<uint64_t, kTileThreads, kKeysPerThread, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_packed + extra),
+                RSX_INITIALIZATION_FAILED);
+        RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8_stay_kernel<uint64_t, kTileThreads, kKeysPerThread, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_packed + extra),
                 RSX_INITIALIZATION_FAILED);
     }
     constexpr int lds_v3k = static_cast<int>(rsx::Reorder8V3Layout<Key, kTileThreads, kKeysPerThread, false>::BYTES);
@@ -790,20 +811,50 @@ int sort8_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext
                                        static_cast<const Key*>(in), static_cast<Key*>(out), nullptr, nullptr, e->table8, e->gsum8, e->cbase8, chunk_groups,
                                        count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip);
                 }
-            } else if (sizeof(Key) == 4 && e->has_payload && e->r8_packed) {
-                // uint32 key + payload as one 64-bit element (rsx::reorder8_kernel<.., PACKED32>)
-                constexpr size_t lds_packed = rsx::Reorder8Layout<uint64_t, kTileThreads, kKeysPerThread>::BYTES;
-                hipLaunchKernelGGL((rsx::reorder8_kernel<uint64_t, kTileThreads, kKeysPerThread, false, true>), dim3(g.blocks), dim3(kTileThreads), lds_packed + r8_extra_lds_for(e, true, false), e->stream,
-                                   static_cast<const uint64_t*>(in), static_cast<uint64_t*>(out), pin, pout, e->table8, e->gsum8, e->cbase8, chunk_groups,
-                                   count, g.ntiles, g.tiles_per_xcd, g.remap, shift, static_cast<uint64_t>(flip));
-            } else if (e->has_payload) {
-                hipLaunchKernelGGL((rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, true>), dim3(g.blocks), dim3(kTileThreads), L::BYTES + r8_extra_lds_for(e, sizeof(Key) == 8, true), e->stream,
-                                   static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->table8, e->gsum8, e->cbase8, chunk_groups,
-                                   count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip);
             } else {
-                hipLaunchKernelGGL((rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, false>), dim3(g.blocks), dim3(kTileThreads), L::BYTES + r8_extra_lds_for(e, sizeof(Key) == 8, false), e->stream,
-                                   static_cast<const Key*>(in), static_cast<Key*>(out), nullptr, nullptr, e->table8, e->gsum8, e->cbase8, chunk_groups,
-                                   count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip);
+                // kernel 1.  stay > 0: a grid of that many workgroups per CU walks the tiles and prefetches (reorder8_stay_kernel)
+                const bool packed = sizeof(Key) == 4 && e->has_payload && e->r8_packed;
+                const bool elem64 = packed || sizeof(Key) == 8;
+                const int stay = r8_stay_for(e, elem64, e->has_payload && !packed);
+                const uint32_t stay_blocks = static_cast<uint32_t>(stay) * static_cast<uint32_t>(std::max(e->num_cus, static_cast<int>(rsx::kNumXcd))) / rsx::kNumXcd * rsx::kNumXcd;
+                const bool use_stay = stay > 0 && stay_blocks < g.blocks;
+                const dim3 grid(use_stay ? stay_blocks : g.blocks);
+                if (packed) {
+                    // uint32 key + payload as one 64-bit element (rsx::reorder8_kernel<.., PACKED32>)
+                    constexpr size_t lds_packed = rsx::Reorder8Layout<uint64_t, kTileThreads, kKeysPerThread>::BYTES;
+                    const size_t lds = lds_packed + r8_extra_lds_for(e, true, false);
+                    if (use_stay) {
+                        hipLaunchKernelGGL((rsx::reorder8_stay_kernel<uint64_t, kTileThreads, kKeysPerThread, false, true>), grid, dim3(kTileThreads), lds, e->stream,
+                                           static_cast<const uint64_t*>(in), static_cast<uint64_t*>(out), pin, pout, e->table8, e->gsum8, e->cbase8, chunk_groups,
+                                           count, g.ntiles, g.tiles_per_xcd, g.remap, shift, static_cast<uint64_t>(flip));
+                    } else {
+                        hipLaunchKernelGGL((rsx::reorder8_kernel<uint64_t, kTileThreads, kKeysPerThread, false, true>), grid, dim3(kTileThreads), lds, e->stream,
+                                           static_cast<const uint64_t*>(in), static_cast<uint64_t*>(out), pin, pout, e->table8, e->gsum8, e->cbase8, chunk_groups,
+                                           count, g.ntiles, g.tiles_per_xcd, g.remap, shift, static_cast<uint64_t>(flip));
+                    }
+                } else if (e->has_payload) {
+                    const size_t lds = L::BYTES + r8_extra_lds_for(e, sizeof(Key) == 8, true);
+                    if (use_stay) {
+                        hipLaunchKernelGGL((rsx::reorder8_stay_kernel<Key, kTileThreads, kKeysPerThread, true>), grid, dim3(kTileThreads), lds, e->stream,
+                                           static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->table8, e->gsum8, e->cbase8, chunk_groups,
+                                           count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip);
+                    } else {
+                        hipLaunchKernelGGL((rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, true>), grid, dim3(kTileThreads), lds, e->stream,
+                                           static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->table8, e->gsum8, e->cbase8, chunk_groups,
+                                           count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip);
+                    }
+                } else {
+                    const size_t lds = L::BYTES + r8_extra_lds_for(e, sizeof(Key) == 8, false);
+                    if (use_stay) {
+                        hipLaunchKernelGGL((rsx::reorder8_stay_kernel<Key, kTileThreads, kKeysPerThread, false>), grid, dim3(kTileThreads), lds, e->stream,
+                                           static_cast<const Key*>(in), static_cast<Key*>(out), nullptr, nullptr, e->table8, e->gsum8, e->cbase8, chunk_groups,
+                                           count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip);
+                    } else {
+                        hipLaunchKernelGGL((rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, false>), grid, dim3(kTileThreads), lds, e->stream,
+                                           static_cast<const Key*>(in), static_cast<Key*>(out), nullptr, nullptr, e->table8, e->gsum8, e->cbase8, chunk_groups,
+                                           count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip);
+                    }
+                }
             }
         }
         RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
@@ -1292,8 +1343,9 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
     if (const char* env = std::getenv("RSX_SMALL_TILE_MAX_KEYS")) e->small_tile_max_keys = std::min<uint64_t>(std::strtoull(env, nullptr, 10), static_cast<uint64_t>(rsx::kSelfScanMaxTiles) * kTileThreads * kSmallKeysPerThread);
     if (const char* env = std::getenv("RSX_SELF_SCAN_MAX")) e->self_scan_max = std::min<uint32_t>(static_cast<uint32_t>(std::atoi(env)), rsx::kSelfScanMaxTiles);
     if (const char* env = std::getenv("RSX_RADIX_BITS")) e->radix_bits = std::atoi(env) == 8 ? 8 : 4;
-    if (const char* env = std::getenv("RSX_REORDER_EXTRA_LDS_KB")) e->reorder_extra_lds = static_cast<size_t>(std::max(0, std::min(64, std::atoi(env)))) << 10;
+    if (const char* env = std::getenv("RSX_REORDER_EXTRA_LDS_KB")) e->reorder_extra_lds = std::atoi(env) < 0 ? -1L : static_cast<long>(std::min(64, std::atoi(env))) * 1024;
     if (const char* env = std::getenv("RSX_R8_PACKED")) e->r8_packed = std::atoi(env) != 0;
+    if (const char* env = std::getenv("RSX_R8_STAY")) e->r8_stay = std::max(-1, std::min(8, std::atoi(env)));
     if (const char* env = std::getenv("RSX_R8_EXTRA_LDS_KB")) e->r8_extra_lds = std::atoi(env) < 0 ? -1L : static_cast<long>(std::min(96, std::atoi(env))) * 1024;
     if (const char* env = std::getenv("RSX_REORDER8_V")) e->reorder8_version = std::max(1, std::min(3, std::atoi(env)));
     if (const char* env = std::getenv("RSX_RADIX8_MIN_KEYS")) e->radix8_min_keys = std::max<uint64_t>(std::strtoull(env, nullptr, 10), kTileKeys);
@@ -1381,6 +1433,7 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
             return bail(RSX_INITIALIZATION_FAILED, "hipOccupancyMaxActiveBlocksPerMultiprocessor(scan_fused_kernel)", err);
         if ((err = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess)
             return bail(RSX_INITIALIZATION_FAILED, "hipDeviceGetAttribute(multiProcessorCount)", err);
+        e->num_cus = cus;
         e->fused_scan_resident = static_cast<uint32_t>(std::max(per_cu, 0)) * static_cast<uint32_t>(std::max(cus, 0));
         e->fused_scan_limit = std::min<uint32_t>(e->fused_scan_resident / 2, rsx::kFusedScanMaxGroups);
         if (const char* env = std::getenv("RSX_FUSED_SCAN_MAX_GROUPS"))
@@ -1532,6 +1585,10 @@ int rsx_set_option(rsx_engine* e, int option, int64_t value)
     case RSX_OPT_REORDER8_KERNEL:
         if (value < 1 || value > 3) return fail(RSX_CALCULATION_FAILED, "rsx_set_option: the 8-bit scatter kernel is 1, 2 or 3");
         e->reorder8_version = static_cast<int>(value);
+        return RSX_OK;
+    case RSX_OPT_REORDER8_STAY:
+        if (value < -1 || value > 8) return fail(RSX_CALCULATION_FAILED, "rsx_set_option: workgroups per CU of the staying 8-bit scatter: -1 (policy), 0 (off) .. 8");
+        e->r8_stay = static_cast<int>(value);
         return RSX_OK;
     case RSX_OPT_INLINE_SCAN: e->inline_scan = value != 0; return RSX_OK;
     case RSX_OPT_INLINE_SCAN_MAX_GROUPS:

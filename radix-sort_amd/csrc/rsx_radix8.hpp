@@ -216,54 +216,37 @@ struct Reorder8Layout {
     static_assert(KPT == 16 && THREADS == kRadix8, "row geometry; one thread per digit handles the tile's table row");
 };
 
-// PACKED32 (uint32 keys WITH payload, instantiated as Key = uint64_t, PAYLOAD = false): key and payload travel through the two ranking
-// rounds as ONE 64-bit element (key in the low word, where the digit is taken; payload in the high word) — `in` / `out` really point at
-// uint32 keys, `pin` / `pout` at the payloads.  One 8-byte LDS access per element and round instead of two 4-byte ones, and none of the
-// payload's own trips (4 barriers fewer per tile): the uint32 + payload scatter then costs what the uint64 keys-only one costs.
-template <typename Key, int THREADS, int KPT, bool PAYLOAD, bool PACKED32 = false>
-__global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREADS, KPT>::MIN_WAVES > 4 ? 4 : Reorder8Layout<Key, THREADS, KPT>::MIN_WAVES))) void reorder8_kernel(
-    const Key* __restrict__ in, Key* __restrict__ out, const uint32_t* __restrict__ pin, uint32_t* __restrict__ pout,
-    const uint32_t* __restrict__ table8, const uint32_t* __restrict__ gsum8, const uint32_t* __restrict__ cbase8,
-    uint32_t chunk_groups, uint64_t n, uint32_t ntiles, uint32_t tiles_per_xcd, int remap, int shift, Key flip)
+// One tile's keys (and payloads) in registers as loaded — sign flip not yet applied — with this thread's entry of the tile's table row.
+template <typename Key, int KPT, bool PAYLOAD>
+struct Reorder8Regs {
+    Key k[KPT];
+    uint32_t pl[PAYLOAD ? KPT : 1];
+    uint32_t my_base;
+    uint32_t valid;
+};
+
+// Issue the loads of tile `tile` (nothing here waits for them; reorder8_sort_tile's first use does).
+template <typename Key, int THREADS, int KPT, bool PAYLOAD, bool PACKED32>
+__device__ __forceinline__ void reorder8_fetch(Reorder8Regs<Key, KPT, PAYLOAD>& t, const Key* __restrict__ in, const uint32_t* __restrict__ pin,
+                                               const uint32_t* __restrict__ table8, const uint32_t* __restrict__ gsum8, const uint32_t* __restrict__ cbase8,
+                                               uint32_t chunk_groups, uint64_t n, uint32_t tile, Key flip)
 {
-    using L = Reorder8Layout<Key, THREADS, KPT>;
-    static_assert(!PACKED32 || (sizeof(Key) == 8 && !PAYLOAD), "packed (uint32 key, payload) elements are 64-bit and carry their payload themselves");
     constexpr int TILE = THREADS * KPT;
-    constexpr int KD = L::KD;
     constexpr int VEC = KeyVec<Key>::N;
     constexpr int NV = KPT / VEC;
-    constexpr uint32_t CNT_ROW_BYTES = THREADS * 4;
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    uint32_t* xbuf = smem;
-    uint32_t* cnt = smem + L::XBUF_DW;
-    uint32_t* wtot = cnt + L::CNT_DW;
-    uint32_t* gb = wtot + 16;                     // per 8-bit digit: (global slot of the tile's first key with it) - (its local slot)
     const uint32_t tid = threadIdx.x;
-    const uint32_t tile = tile_of_block(blockIdx.x, tiles_per_xcd, remap & ~2);
-    if (tile >= ntiles) {
-        return;
-    }
-    if (!lds_base_is_zero(smem)) {
-        __builtin_trap();           // lds_store_at addresses the image from LDS address 0
-    }
     const uint64_t base = static_cast<uint64_t>(tile) * TILE;
     const uint64_t left = n - base;
     const uint32_t valid = left < static_cast<uint64_t>(TILE) ? static_cast<uint32_t>(left) : static_cast<uint32_t>(TILE);
     const bool full = (valid == TILE);
-    // Inside the kernel keys are held with the sign bit flipped (k ^ flip: unsigned order = numeric order), so the
-    // digits are plain bit fields; the flip is undone on the way out.  Unsigned types skip both (flip == 0, uniform).
-    const Key pad_key = static_cast<Key>(~Key{0});        // digit 255, behind every real key of the tile
-    const bool hi = !PACKED32 && sizeof(Key) == 8 && shift >= 32;      // the byte never straddles the halves of a 64-bit key
-    const uint32_t sh = static_cast<uint32_t>(shift) & 31u;
-
+    t.valid = valid;
+    // pads sort behind every real key of the tile (digit 255 once the flip below is applied)
+    const Key pad_raw = static_cast<Key>(~Key{0}) ^ flip;
     // this thread's digit of the tile's table row (latency hides under the key loads): global slot of the tile's first key with
     // that digit minus its tile-local slot
     const uint32_t group = tile / kScan8Tiles;
-    const uint32_t my_base = table8[static_cast<uint64_t>(tile) * kRadix8 + tid] + gsum8[static_cast<uint64_t>(group) * kRadix8 + tid] +
-                             cbase8[static_cast<uint64_t>(group / chunk_groups) * kRadix8 + tid];      // smaller digits + this digit in earlier chunks
-
-    Key k[KPT];
-    uint32_t pl[PAYLOAD ? KPT : 1];
+    t.my_base = table8[static_cast<uint64_t>(tile) * kRadix8 + tid] + gsum8[static_cast<uint64_t>(group) * kRadix8 + tid] +
+                cbase8[static_cast<uint64_t>(group / chunk_groups) * kRadix8 + tid];      // smaller digits + this digit in earlier chunks
     if constexpr (PACKED32) {
         const uint32_t* in32 = reinterpret_cast<const uint32_t*>(in);
         if (full) {
@@ -273,14 +256,14 @@ __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREAD
                 const U32x4 b = *reinterpret_cast<const U32x4*>(pin + base + tid * KPT + q * 4);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    k[q * 4 + c] = (static_cast<Key>(b.v[c]) << 32) | static_cast<Key>(a.v[c] ^ static_cast<uint32_t>(flip));
+                    t.k[q * 4 + c] = (static_cast<Key>(b.v[c]) << 32) | static_cast<Key>(a.v[c]);
                 }
             }
         } else {
 #pragma unroll
             for (int i = 0; i < KPT; ++i) {
                 const uint32_t li = tid * KPT + i;
-                k[i] = li < valid ? ((static_cast<Key>(pin[base + li]) << 32) | static_cast<Key>(in32[base + li] ^ static_cast<uint32_t>(flip))) : pad_key;
+                t.k[i] = li < valid ? ((static_cast<Key>(pin[base + li]) << 32) | static_cast<Key>(in32[base + li])) : pad_raw;
             }
         }
     } else if (full) {
@@ -289,36 +272,61 @@ __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREAD
             const KeyVec<Key> v = load_keys16(in + base + tid * KPT + j * VEC);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-                k[j * VEC + e] = v.k[e];
+                t.k[j * VEC + e] = v.k[e];
             }
         }
         if constexpr (PAYLOAD) {
 #pragma unroll
             for (int q = 0; q < KPT / 4; ++q) {
                 const U32x4 x = *reinterpret_cast<const U32x4*>(pin + base + tid * KPT + q * 4);
-                pl[q * 4 + 0] = x.v[0];
-                pl[q * 4 + 1] = x.v[1];
-                pl[q * 4 + 2] = x.v[2];
-                pl[q * 4 + 3] = x.v[3];
-            }
-        }
-        if (flip != Key{0}) {
-#pragma unroll
-            for (int i = 0; i < KPT; ++i) {
-                k[i] ^= flip;
+                t.pl[q * 4 + 0] = x.v[0];
+                t.pl[q * 4 + 1] = x.v[1];
+                t.pl[q * 4 + 2] = x.v[2];
+                t.pl[q * 4 + 3] = x.v[3];
             }
         }
     } else {
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
             const uint32_t li = tid * KPT + i;
-            k[i] = li < valid ? static_cast<Key>(in[base + li] ^ flip) : pad_key;
+            t.k[i] = li < valid ? in[base + li] : pad_raw;
             if constexpr (PAYLOAD) {
-                pl[i] = li < valid ? pin[base + li] : 0u;
+                t.pl[i] = li < valid ? pin[base + li] : 0u;
             }
         }
     }
-    gb[tid] = my_base;           // (read after several barriers)
+}
+
+// Rank the tile's keys on the 8-bit digit at `shift` (two stable 4-bit rounds through the LDS image), then store them — and their
+// payloads — as runs at their global slots.  Ends with a barrier: the image, the counters and gb[] are free for the next tile.
+template <typename Key, int THREADS, int KPT, bool PAYLOAD, bool PACKED32>
+__device__ __forceinline__ void reorder8_sort_tile(Reorder8Regs<Key, KPT, PAYLOAD>& t, uint32_t* smem, Key* __restrict__ out, uint32_t* __restrict__ pout, int shift, Key flip)
+{
+    using L = Reorder8Layout<Key, THREADS, KPT>;
+    constexpr int TILE = THREADS * KPT;
+    constexpr int KD = L::KD;
+    constexpr int VEC = KeyVec<Key>::N;
+    constexpr int NV = KPT / VEC;
+    constexpr uint32_t CNT_ROW_BYTES = THREADS * 4;
+    uint32_t* xbuf = smem;
+    uint32_t* cnt = smem + L::XBUF_DW;
+    uint32_t* wtot = cnt + L::CNT_DW;
+    uint32_t* gb = wtot + 16;                     // per 8-bit digit: (global slot of the tile's first key with it) - (its local slot)
+    const uint32_t tid = threadIdx.x;
+    const uint32_t valid = t.valid;
+    const bool full = (valid == TILE);
+    // Inside the kernel keys are held with the sign bit flipped (k ^ flip: unsigned order = numeric order), so the
+    // digits are plain bit fields; the flip is undone on the way out.  Unsigned types skip both (flip == 0, uniform).
+    const bool hi = !PACKED32 && sizeof(Key) == 8 && shift >= 32;      // the byte never straddles the halves of a 64-bit key
+    const uint32_t sh = static_cast<uint32_t>(shift) & 31u;
+    if (flip != Key{0}) {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            t.k[i] ^= flip;
+        }
+    }
+    gb[tid] = t.my_base;         // (read after several barriers)
+
     u32_alias* cnt32 = reinterpret_cast<u32_alias*>(cnt);
     unsigned char* cbytes = reinterpret_cast<unsigned char*>(cnt);
     // image: slot s at dword s*KD + 4*(s/16) (rows of KPT keys + 16 bytes); slot i = r*THREADS + tid -> per-thread base + r * OUT_STRIDE
@@ -343,7 +351,7 @@ __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREAD
             uint32_t d_last = 0;
 #pragma unroll
             for (int i = 0; i < KPT; ++i) {
-                const uint32_t d = __builtin_amdgcn_ubfe(field_word(k[i], hi), rsh, 4u);
+                const uint32_t d = __builtin_amdgcn_ubfe(field_word(t.k[i], hi), rsh, 4u);
                 const uint32_t sh4 = d << 2;
                 slot[i] = static_cast<uint32_t>(seen >> sh4) & 15u;
                 if (i + 1 < KPT) {
@@ -384,7 +392,7 @@ __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREAD
             uint32_t first_of_digit[KPT];
 #pragma unroll
             for (int i = 0; i < KPT; ++i) {
-                const uint32_t w = field_word(k[i], hi);
+                const uint32_t w = field_word(t.k[i], hi);
                 const uint32_t l3 = __builtin_amdgcn_ubfe(w, rsh, 3u);
                 const uint32_t h = __builtin_amdgcn_ubfe(w, rsh + 3u, 1u);
                 first_of_digit[i] = *reinterpret_cast<const u16_alias*>(cbytes + (l3 * CNT_ROW_BYTES + tid * 4u) + h * 2u);
@@ -397,11 +405,11 @@ __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREAD
             for (int i = 0; i < KPT; ++i) {
                 // byte offset of slot s: (s*KD + 4*(s>>4)) * 4
                 if (padded) {
-                    lds_store_at<Key>(add_lshl<(KD == 1 ? 2 : 3)>(slot[i], slot[i] >> PADSH), k[i]);
+                    lds_store_at<Key>(add_lshl<(KD == 1 ? 2 : 3)>(slot[i], slot[i] >> PADSH), t.k[i]);
                 } else if constexpr (KD == 1) {
-                    lds_store_at<Key>(add_lshl<2>(slot[i], (slot[i] >> 2) & ~3u), k[i]);
+                    lds_store_at<Key>(add_lshl<2>(slot[i], (slot[i] >> 2) & ~3u), t.k[i]);
                 } else {
-                    lds_store_at<Key>(add_lshl<2>(slot[i] << 1, (slot[i] >> 2) & ~3u), k[i]);
+                    lds_store_at<Key>(add_lshl<2>(slot[i] << 1, (slot[i] >> 2) & ~3u), t.k[i]);
                 }
             }
         }
@@ -412,7 +420,7 @@ __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREAD
                 const KeyVec<Key> v = *reinterpret_cast<const KeyVec<Key>*>(xbuf + tid * L::ROW_DW + j * 4);
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
-                    k[j * VEC + e] = v.k[e];
+                    t.k[j * VEC + e] = v.k[e];
                 }
             }
         } else {
@@ -466,7 +474,7 @@ __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREAD
             if constexpr (PAYLOAD) {
 #pragma unroll
                 for (int r = 0; r < KPT; ++r) {
-                    k[r] = static_cast<Key>(g[r]);          // keys are gone; keep each slot's destination for its payload
+                    t.k[r] = static_cast<Key>(g[r]);          // keys are gone; keep each slot's destination for its payload
                 }
             }
         }
@@ -475,9 +483,9 @@ __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREAD
 #pragma unroll
             for (int i = 0; i < KPT; ++i) {
                 if (padded) {
-                    lds_store_at<uint32_t>(add_lshl<2>(slot[i], slot[i] >> 5), pl[i]);
+                    lds_store_at<uint32_t>(add_lshl<2>(slot[i], slot[i] >> 5), t.pl[i]);
                 } else {
-                    lds_store_at<uint32_t>(add_lshl<2>(slot[i], (slot[i] >> 2) & ~3u), pl[i]);
+                    lds_store_at<uint32_t>(add_lshl<2>(slot[i], (slot[i] >> 2) & ~3u), t.pl[i]);
                 }
             }
             __syncthreads();
@@ -485,10 +493,10 @@ __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREAD
 #pragma unroll
                 for (int q = 0; q < KPT / 4; ++q) {
                     const U32x4 x = *reinterpret_cast<const U32x4*>(xbuf + tid * (KPT + 4) + q * 4);
-                    pl[q * 4 + 0] = x.v[0];
-                    pl[q * 4 + 1] = x.v[1];
-                    pl[q * 4 + 2] = x.v[2];
-                    pl[q * 4 + 3] = x.v[3];
+                    t.pl[q * 4 + 0] = x.v[0];
+                    t.pl[q * 4 + 1] = x.v[1];
+                    t.pl[q * 4 + 2] = x.v[2];
+                    t.pl[q * 4 + 3] = x.v[3];
                 }
             } else {
                 const uint32_t pbase = padded ? tid + (tid >> 5) : tid + ((tid >> 4) << 2);
@@ -496,12 +504,90 @@ __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREAD
 #pragma unroll
                 for (int r = 0; r < KPT; ++r) {
                     if (full || static_cast<uint32_t>(r) * THREADS + tid < valid) {
-                        pout[static_cast<uint32_t>(k[r])] = xbuf[pbase + static_cast<uint32_t>(r) * pstride];
+                        pout[static_cast<uint32_t>(t.k[r])] = xbuf[pbase + static_cast<uint32_t>(r) * pstride];
                     }
                 }
             }
         }
         __syncthreads();               // image and counters are free for the second round
+    }
+}
+
+// PACKED32 (uint32 keys WITH payload, instantiated as Key = uint64_t, PAYLOAD = false): key and payload travel through the two ranking
+// rounds as ONE 64-bit element (key in the low word, where the digit is taken; payload in the high word) — `in` / `out` really point at
+// uint32 keys, `pin` / `pout` at the payloads.  One 8-byte LDS access per element and round instead of two 4-byte ones, and none of the
+// payload's own trips (4 barriers fewer per tile): the uint32 + payload scatter then costs what the uint64 keys-only one costs.
+template <typename Key, int THREADS, int KPT, bool PAYLOAD, bool PACKED32 = false>
+__global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREADS, KPT>::MIN_WAVES > 4 ? 4 : Reorder8Layout<Key, THREADS, KPT>::MIN_WAVES))) void reorder8_kernel(
+    const Key* __restrict__ in, Key* __restrict__ out, const uint32_t* __restrict__ pin, uint32_t* __restrict__ pout,
+    const uint32_t* __restrict__ table8, const uint32_t* __restrict__ gsum8, const uint32_t* __restrict__ cbase8,
+    uint32_t chunk_groups, uint64_t n, uint32_t ntiles, uint32_t tiles_per_xcd, int remap, int shift, Key flip)
+{
+    static_assert(!PACKED32 || (sizeof(Key) == 8 && !PAYLOAD), "packed (uint32 key, payload) elements are 64-bit and carry their payload themselves");
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const uint32_t tile = tile_of_block(blockIdx.x, tiles_per_xcd, remap & ~2);
+    if (tile >= ntiles) {
+        return;
+    }
+    if (!lds_base_is_zero(smem)) {
+        __builtin_trap();           // lds_store_at addresses the image from LDS address 0
+    }
+    Reorder8Regs<Key, KPT, PAYLOAD> t;
+    reorder8_fetch<Key, THREADS, KPT, PAYLOAD, PACKED32>(t, in, pin, table8, gsum8, cbase8, chunk_groups, n, tile, flip);
+    reorder8_sort_tile<Key, THREADS, KPT, PAYLOAD, PACKED32>(t, smem, out, pout, shift, flip);
+}
+
+// The same scatter as a grid that stays: gridDim.x = 8 * (workgroups per XCD) workgroups walk their XCD's tile range with that stride, so the
+// tiles in flight on an XCD at any moment are still neighbours (whose partial sectors merge in its L2), and each workgroup issues the loads
+// of its NEXT tile before it ranks the current one: the HBM latency of a tile (a third of its residency at two waves per SIMD, where the
+// 64-bit variants run) hides under the previous tile's LDS work instead of under other workgroups.
+template <typename Key, int THREADS, int KPT, bool PAYLOAD, bool PACKED32 = false>
+__global__ __launch_bounds__(THREADS, 2) void reorder8_stay_kernel(
+    const Key* __restrict__ in, Key* __restrict__ out, const uint32_t* __restrict__ pin, uint32_t* __restrict__ pout,
+    const uint32_t* __restrict__ table8, const uint32_t* __restrict__ gsum8, const uint32_t* __restrict__ cbase8,
+    uint32_t chunk_groups, uint64_t n, uint32_t ntiles, uint32_t tiles_per_xcd, int remap, int shift, Key flip)
+{
+    static_assert(!PACKED32 || (sizeof(Key) == 8 && !PAYLOAD), "packed (uint32 key, payload) elements are 64-bit and carry their payload themselves");
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    if (!lds_base_is_zero(smem)) {
+        __builtin_trap();           // lds_store_at addresses the image from LDS address 0
+    }
+    // positions p = first, first + stride, ... < range; position p of XCD x is tile x * range + (p + x * phase) mod range (tile_of_block's order)
+    const bool by_xcd = (remap & 1) != 0;
+    const uint32_t x = by_xcd ? blockIdx.x % kNumXcd : 0u;
+    const uint32_t range = by_xcd ? tiles_per_xcd : ntiles;
+    const uint32_t stride = by_xcd ? gridDim.x / kNumXcd : gridDim.x;
+    const uint32_t phase = by_xcd ? x * (static_cast<uint32_t>(remap) >> 8) : 0u;          // host keeps 7 * phase < tiles_per_xcd
+    const auto tile_at = [&](uint32_t p) {
+        uint32_t j = p + phase;
+        j = j >= range ? j - range : j;
+        return x * range + j;
+    };
+    const auto next_position = [&](uint32_t p) {         // (only the last XCD's range reaches past ntiles)
+        while (p < range && tile_at(p) >= ntiles) {
+            p += stride;
+        }
+        return p;
+    };
+    uint32_t p = next_position(by_xcd ? blockIdx.x / kNumXcd : blockIdx.x);
+    if (p >= range) {
+        return;
+    }
+    Reorder8Regs<Key, KPT, PAYLOAD> cur;
+    reorder8_fetch<Key, THREADS, KPT, PAYLOAD, PACKED32>(cur, in, pin, table8, gsum8, cbase8, chunk_groups, n, tile_at(p), flip);
+    for (;;) {
+        const uint32_t pn = next_position(p + stride);
+        const bool more = pn < range;
+        Reorder8Regs<Key, KPT, PAYLOAD> nxt;
+        if (more) {
+            reorder8_fetch<Key, THREADS, KPT, PAYLOAD, PACKED32>(nxt, in, pin, table8, gsum8, cbase8, chunk_groups, n, tile_at(pn), flip);
+        }
+        reorder8_sort_tile<Key, THREADS, KPT, PAYLOAD, PACKED32>(cur, smem, out, pout, shift, flip);
+        if (!more) {
+            break;
+        }
+        cur = nxt;
+        p = pn;
     }
 }
 

@@ -1155,3 +1155,39 @@ def test_8bit_scatter_kernel_variants_are_stable_and_exact(mod, oracle, kernel, 
     with mod.Engine(dt, 4096) as e:
         with pytest.raises(mod.RadixSortError):
             e.set_option(mod.OPT_REORDER8_KERNEL, 4)
+
+
+@pytest.mark.parametrize("dt,n,stay", [("uint32", (1 << 22) + 4099, 2), ("int32", (1 << 21) + 1, 1), ("uint64", (1 << 22) - 4097, 2), ("int64", 3 * (1 << 20) + 77, 1),
+                                       ("uint32", 9 * 4096 * 8 + 5, 1)])
+def test_8bit_scatter_as_a_staying_grid_is_exact(mod, oracle, dt, n, stay):
+    """RSX_OPT_REORDER8_STAY: N workgroups per CU walk the tiles of their XCD's range and prefetch the next tile while they rank the
+    current one — same keys, same stable payload order as the one-workgroup-per-tile launch; ragged last tile, XCD ranges that do not
+    divide (the last range reaches past the last tile), keys only / payload / uint32 key and payload kept apart (RSX_R8_PACKED=0), and a
+    size whose grid is smaller than the staying one (falls back to one workgroup per tile)."""
+    import os
+    keys = oracle.dataset("SeededUniform", dt, n, seed=stay + n % 17)
+    keys[::5] = keys[3]
+    want_k = np.sort(keys)
+    want_p = np.argsort(keys, kind="stable").astype(np.uint32)
+    for payload, packed in [(False, "1"), (True, "1")] + ([(True, "0")] if np.dtype(dt).itemsize == 4 else []):
+        os.environ["RSX_R8_PACKED"] = packed
+        try:
+            e = mod.Engine(dt, n, payload=payload)
+        finally:
+            del os.environ["RSX_R8_PACKED"]
+        with e:
+            e.set_option(mod.OPT_RADIX_BITS, 8)
+            e.set_option(mod.OPT_REORDER8_STAY, stay)
+            if payload:
+                e.upload(keys, np.arange(n, dtype=np.uint32))
+                e.sort()
+                ks, ps = e.download(want_perm=True)
+                assert np.array_equal(ps, want_p)
+            else:
+                e.upload(keys)
+                e.sort()
+                ks = e.download()
+            assert np.array_equal(ks, want_k)
+            for bad in (-2, 9):
+                with pytest.raises(mod.RadixSortError):
+                    e.set_option(mod.OPT_REORDER8_STAY, bad)
