@@ -211,6 +211,7 @@ struct rsx_engine {
     int r8_packed = 1;          // 8-bit scatter of uint32 keys WITH payload: key and payload as one 64-bit element through the ranking rounds (env RSX_R8_PACKED; kernel 1 only)
     int lds_atomics_ordered = -1;               // -1 not probed yet; 1: ds_add_rtn serves lanes in ascending lane order on this device (lds_atomic_order_probe_kernel); 0: it does not, kernel 3 is refused
     bool radix8_ready = false;                  // the five tables below exist and the reorder8 kernels may use their LDS
+    uint32_t* tickets8 = nullptr;               // staying 8-bit scatter: [pass of the chain][XCD] tile tickets, zeroed at the start of every sort that uses them
     uint32_t* counts8 = nullptr;                // 8-bit digits: raw counts [tile][256] (allocated on first use)
     uint32_t* table8 = nullptr;                 //   group-local exclusive prefixes [tile][256]
     uint32_t* gsum8 = nullptr;                  //   per scan group: totals, then prefixes inside the group's chunk [group][256]
@@ -675,6 +676,8 @@ size_t r8_extra_lds_for(const rsx_engine* e, bool elem64, bool separate_payload)
     return separate_payload ? (16u << 10) : (8u << 10);
 }
 
+constexpr size_t kTickets8Bytes = 8 * rsx::kNumXcd * sizeof(uint32_t);           // at most 8 byte passes (64-bit keys)
+
 // workgroups per CU of the staying grid of the default 8-bit scatter (0 = one workgroup per tile), by variant
 int r8_stay_for(const rsx_engine* e, bool elem64, bool separate_payload)
 {
@@ -699,6 +702,7 @@ int ensure_radix8(rsx_engine* e)
     if (!e->gsum8) RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->gsum8), groups), RSX_INITIALIZATION_FAILED);
     if (!e->csum8) RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->csum8), rsx::kScan8MaxChunks * rsx::kRadix8 * 4), RSX_INITIALIZATION_FAILED);
     if (!e->cbase8) RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->cbase8), rsx::kScan8MaxChunks * rsx::kRadix8 * 4), RSX_INITIALIZATION_FAILED);
+    if (!e->tickets8) RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->tickets8), kTickets8Bytes), RSX_INITIALIZATION_FAILED);
     RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L::BYTES) + extra), RSX_INITIALIZATION_FAILED);
     RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, true>),
@@ -760,6 +764,13 @@ int sort8_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext
     Bracket whole(e, PH_TOTAL);
     e->counted_keys = nullptr;
     const Key flip = flip_mask<Key>(e);
+    // kernel 1 as a staying grid (reorder8_stay_kernel): that many workgroups per CU draw tile tickets, which start from zero in every sort
+    const bool r8_packed = sizeof(Key) == 4 && e->has_payload && e->r8_packed;
+    const int stay = (e->reorder8_version == 1 || (e->reorder8_version == 3 && e->lds_atomics_ordered != 1))
+                         ? r8_stay_for(e, r8_packed || sizeof(Key) == 8, e->has_payload && !r8_packed) : 0;
+    const uint32_t stay_blocks = static_cast<uint32_t>(stay) * static_cast<uint32_t>(std::max(e->num_cus, static_cast<int>(rsx::kNumXcd))) / rsx::kNumXcd * rsx::kNumXcd;
+    const bool use_stay = stay > 0 && stay_blocks < g.blocks;
+    if (use_stay) RSX_TRY(hipMemsetAsync(e->tickets8, 0, kTickets8Bytes, e->stream), RSX_CALCULATION_FAILED);
     for (int pass = e->first_pass; pass < e->last_pass; pass += 2) {
         const bool to_caller = e->final_keys_out && pass + 2 == e->last_pass;
         void* out = to_caller ? e->final_keys_out : e->keys[dst];
@@ -813,11 +824,7 @@ int sort8_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext
                 }
             } else {
                 // kernel 1.  stay > 0: a grid of that many workgroups per CU walks the tiles and prefetches (reorder8_stay_kernel)
-                const bool packed = sizeof(Key) == 4 && e->has_payload && e->r8_packed;
-                const bool elem64 = packed || sizeof(Key) == 8;
-                const int stay = r8_stay_for(e, elem64, e->has_payload && !packed);
-                const uint32_t stay_blocks = static_cast<uint32_t>(stay) * static_cast<uint32_t>(std::max(e->num_cus, static_cast<int>(rsx::kNumXcd))) / rsx::kNumXcd * rsx::kNumXcd;
-                const bool use_stay = stay > 0 && stay_blocks < g.blocks;
+                const bool packed = r8_packed;
                 const dim3 grid(use_stay ? stay_blocks : g.blocks);
                 if (packed) {
                     // uint32 key + payload as one 64-bit element (rsx::reorder8_kernel<.., PACKED32>)
@@ -826,7 +833,7 @@ int sort8_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext
                     if (use_stay) {
                         hipLaunchKernelGGL((rsx::reorder8_stay_kernel<uint64_t, kTileThreads, kKeysPerThread, false, true>), grid, dim3(kTileThreads), lds, e->stream,
                                            static_cast<const uint64_t*>(in), static_cast<uint64_t*>(out), pin, pout, e->table8, e->gsum8, e->cbase8, chunk_groups,
-                                           count, g.ntiles, g.tiles_per_xcd, g.remap, shift, static_cast<uint64_t>(flip));
+                                           count, g.ntiles, g.tiles_per_xcd, g.remap, shift, static_cast<uint64_t>(flip), e->tickets8 + static_cast<size_t>(pass / 2) * rsx::kNumXcd);
                     } else {
                         hipLaunchKernelGGL((rsx::reorder8_kernel<uint64_t, kTileThreads, kKeysPerThread, false, true>), grid, dim3(kTileThreads), lds, e->stream,
                                            static_cast<const uint64_t*>(in), static_cast<uint64_t*>(out), pin, pout, e->table8, e->gsum8, e->cbase8, chunk_groups,
@@ -837,7 +844,7 @@ int sort8_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext
                     if (use_stay) {
                         hipLaunchKernelGGL((rsx::reorder8_stay_kernel<Key, kTileThreads, kKeysPerThread, true>), grid, dim3(kTileThreads), lds, e->stream,
                                            static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->table8, e->gsum8, e->cbase8, chunk_groups,
-                                           count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip);
+                                           count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip, e->tickets8 + static_cast<size_t>(pass / 2) * rsx::kNumXcd);
                     } else {
                         hipLaunchKernelGGL((rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, true>), grid, dim3(kTileThreads), lds, e->stream,
                                            static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->table8, e->gsum8, e->cbase8, chunk_groups,
@@ -848,7 +855,7 @@ int sort8_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext
                     if (use_stay) {
                         hipLaunchKernelGGL((rsx::reorder8_stay_kernel<Key, kTileThreads, kKeysPerThread, false>), grid, dim3(kTileThreads), lds, e->stream,
                                            static_cast<const Key*>(in), static_cast<Key*>(out), nullptr, nullptr, e->table8, e->gsum8, e->cbase8, chunk_groups,
-                                           count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip);
+                                           count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip, e->tickets8 + static_cast<size_t>(pass / 2) * rsx::kNumXcd);
                     } else {
                         hipLaunchKernelGGL((rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, false>), grid, dim3(kTileThreads), lds, e->stream,
                                            static_cast<const Key*>(in), static_cast<Key*>(out), nullptr, nullptr, e->table8, e->gsum8, e->cbase8, chunk_groups,
@@ -1516,6 +1523,7 @@ int rsx_destroy(rsx_engine* e)
         if (e->cnt3[i] && hipFree(e->cnt3[i]) != hipSuccess) status = RSX_CLEANUP_FAILED;
     }
     if (e->counts8 && hipFree(e->counts8) != hipSuccess) status = RSX_CLEANUP_FAILED;
+    if (e->tickets8 && hipFree(e->tickets8) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->table8 && hipFree(e->table8) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->gsum8 && hipFree(e->gsum8) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->csum8 && hipFree(e->csum8) != hipSuccess) status = RSX_CLEANUP_FAILED;

@@ -32,6 +32,9 @@ __device__ __forceinline__ uint32_t digit8_of(Key key, int shift, Key flip)
     return static_cast<uint32_t>((key ^ flip) >> shift) & 255u;
 }
 
+#ifndef RSX_H8_PROBE
+#define RSX_H8_PROBE 0
+#endif
 template <typename Key, int THREADS, int KPT>
 __global__ __launch_bounds__(THREADS) void histogram8_kernel(const Key* __restrict__ keys, uint32_t* __restrict__ counts8, uint64_t n, uint32_t ntiles,
                                                               uint32_t tiles_per_xcd, int remap, int shift, Key flip)
@@ -68,7 +71,13 @@ __global__ __launch_bounds__(THREADS) void histogram8_kernel(const Key* __restri
             for (int e = 0; e < VEC; ++e) {
                 const uint32_t d = digit8_of(v[j].k[e], shift, flip);
                 if (spread) {
+#if RSX_H8_PROBE == 1          // probe builds (wrong counts): 1 = a plain LDS store instead of the atomic, 2 = nothing but the loads
+                    cnt[d] = d;
+#elif RSX_H8_PROBE == 2
+                    if (d == 0x12345u) cnt[0] = d;
+#else
                     atomicAdd(&cnt[d], 1u);
+#endif
                 } else {
                     const uint32_t first = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(d)));
                     if (__ballot(d != first) == 0ull) {
@@ -221,12 +230,22 @@ template <typename Key, int KPT, bool PAYLOAD>
 struct Reorder8Regs {
     Key k[KPT];
     uint32_t pl[PAYLOAD ? KPT : 1];
-    uint32_t my_base;
+    uint32_t base3[3];          // this thread's digit: table row entry, group sum, chunk base — added up where they are used, not where they are loaded
     uint32_t valid;
 };
 
 // Issue the loads of tile `tile` (nothing here waits for them; reorder8_sort_tile's first use does).
-template <typename Key, int THREADS, int KPT, bool PAYLOAD, bool PACKED32>
+// End of the ragged tile's masked loads (one tile per launch): wait for them here.  Left pending, they reach the join with the whole-tile path, where
+// the compiler then drains vmcnt to 0 BEFORE it issues the whole tile's key loads (a register of theirs is a destination of the pending ones) — and
+// with that waits for the table-row loads first: +13 % on the packed uint32 + payload scatter.  s_waitcnt vmcnt(0) (gfx9 encoding: expcnt 7, lgkmcnt 15).
+__device__ __forceinline__ void reorder8_partial_tile_loaded()
+{
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+}
+
+// FULL_ONLY: the tile is known to be whole — vector loads and no branch (what a prefetch across a loop iteration needs: the wait counters of
+// loads issued under a branch are merged conservatively at the join, and the first use behind it would wait for everything).
+template <typename Key, int THREADS, int KPT, bool PAYLOAD, bool PACKED32, bool FULL_ONLY = false>
 __device__ __forceinline__ void reorder8_fetch(Reorder8Regs<Key, KPT, PAYLOAD>& t, const Key* __restrict__ in, const uint32_t* __restrict__ pin,
                                                const uint32_t* __restrict__ table8, const uint32_t* __restrict__ gsum8, const uint32_t* __restrict__ cbase8,
                                                uint32_t chunk_groups, uint64_t n, uint32_t tile, Key flip)
@@ -237,16 +256,17 @@ __device__ __forceinline__ void reorder8_fetch(Reorder8Regs<Key, KPT, PAYLOAD>& 
     const uint32_t tid = threadIdx.x;
     const uint64_t base = static_cast<uint64_t>(tile) * TILE;
     const uint64_t left = n - base;
-    const uint32_t valid = left < static_cast<uint64_t>(TILE) ? static_cast<uint32_t>(left) : static_cast<uint32_t>(TILE);
-    const bool full = (valid == TILE);
+    const uint32_t valid = (FULL_ONLY || left >= static_cast<uint64_t>(TILE)) ? static_cast<uint32_t>(TILE) : static_cast<uint32_t>(left);
+    const bool full = FULL_ONLY || (valid == TILE);
     t.valid = valid;
     // pads sort behind every real key of the tile (digit 255 once the flip below is applied)
     const Key pad_raw = static_cast<Key>(~Key{0}) ^ flip;
     // this thread's digit of the tile's table row (latency hides under the key loads): global slot of the tile's first key with
     // that digit minus its tile-local slot
     const uint32_t group = tile / kScan8Tiles;
-    t.my_base = table8[static_cast<uint64_t>(tile) * kRadix8 + tid] + gsum8[static_cast<uint64_t>(group) * kRadix8 + tid] +
-                cbase8[static_cast<uint64_t>(group / chunk_groups) * kRadix8 + tid];      // smaller digits + this digit in earlier chunks
+    t.base3[0] = table8[static_cast<uint64_t>(tile) * kRadix8 + tid];
+    t.base3[1] = gsum8[static_cast<uint64_t>(group) * kRadix8 + tid];
+    t.base3[2] = cbase8[static_cast<uint64_t>(group / chunk_groups) * kRadix8 + tid];      // smaller digits + this digit in earlier chunks
     if constexpr (PACKED32) {
         const uint32_t* in32 = reinterpret_cast<const uint32_t*>(in);
         if (full) {
@@ -265,6 +285,7 @@ __device__ __forceinline__ void reorder8_fetch(Reorder8Regs<Key, KPT, PAYLOAD>& 
                 const uint32_t li = tid * KPT + i;
                 t.k[i] = li < valid ? ((static_cast<Key>(pin[base + li]) << 32) | static_cast<Key>(in32[base + li])) : pad_raw;
             }
+            reorder8_partial_tile_loaded();
         }
     } else if (full) {
 #pragma unroll
@@ -294,12 +315,15 @@ __device__ __forceinline__ void reorder8_fetch(Reorder8Regs<Key, KPT, PAYLOAD>& 
                 t.pl[i] = li < valid ? pin[base + li] : 0u;
             }
         }
+        reorder8_partial_tile_loaded();
     }
 }
 
 // Rank the tile's keys on the 8-bit digit at `shift` (two stable 4-bit rounds through the LDS image), then store them — and their
 // payloads — as runs at their global slots.  Ends with a barrier: the image, the counters and gb[] are free for the next tile.
-template <typename Key, int THREADS, int KPT, bool PAYLOAD, bool PACKED32>
+// UNROLL_ROUNDS: both rounds written out.  The staying kernel needs it: on gfx9 (stores count in vmcnt) the compiler drains vmcnt to 0 in the
+// preheader of a loop that stores and uses registers loaded before it — which would end the prefetch of the next tile right there.
+template <typename Key, int THREADS, int KPT, bool PAYLOAD, bool PACKED32, bool UNROLL_ROUNDS = false>
 __device__ __forceinline__ void reorder8_sort_tile(Reorder8Regs<Key, KPT, PAYLOAD>& t, uint32_t* smem, Key* __restrict__ out, uint32_t* __restrict__ pout, int shift, Key flip)
 {
     using L = Reorder8Layout<Key, THREADS, KPT>;
@@ -325,7 +349,7 @@ __device__ __forceinline__ void reorder8_sort_tile(Reorder8Regs<Key, KPT, PAYLOA
             t.k[i] ^= flip;
         }
     }
-    gb[tid] = t.my_base;         // (read after several barriers)
+    gb[tid] = t.base3[0] + t.base3[1] + t.base3[2];          // (read after several barriers)
 
     u32_alias* cnt32 = reinterpret_cast<u32_alias*>(cnt);
     unsigned char* cbytes = reinterpret_cast<unsigned char*>(cnt);
@@ -337,11 +361,8 @@ __device__ __forceinline__ void reorder8_sort_tile(Reorder8Regs<Key, KPT, PAYLOA
 #define RSX_R8_PADDED_FINAL 0      // 1: the second round stages into reorder_kernel's padded image (slot + slot >> PADSH) instead of 16-key rows; both rounds unrolled
 #endif
     constexpr int PADSH = (KD == 1) ? 5 : 4;
-#if RSX_R8_PADDED_FINAL
-#pragma unroll
-#else
-#pragma unroll 1
-#endif
+    constexpr int kRoundsUnrolled = (RSX_R8_PADDED_FINAL || UNROLL_ROUNDS) ? 2 : 1;
+#pragma unroll kRoundsUnrolled
     for (int round = 0; round < 2; ++round) {
         const bool padded = RSX_R8_PADDED_FINAL && round == 1;
         const uint32_t rsh = sh + static_cast<uint32_t>(round) * kRadixBits;      // sh is a multiple of 8: rsh + 4 <= 32
@@ -537,57 +558,80 @@ __global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREAD
     reorder8_sort_tile<Key, THREADS, KPT, PAYLOAD, PACKED32>(t, smem, out, pout, shift, flip);
 }
 
-// The same scatter as a grid that stays: gridDim.x = 8 * (workgroups per XCD) workgroups walk their XCD's tile range with that stride, so the
-// tiles in flight on an XCD at any moment are still neighbours (whose partial sectors merge in its L2), and each workgroup issues the loads
-// of its NEXT tile before it ranks the current one: the HBM latency of a tile (a third of its residency at two waves per SIMD, where the
-// 64-bit variants run) hides under the previous tile's LDS work instead of under other workgroups.
+// The same scatter as a grid that stays: gridDim.x = 8 * (workgroups per XCD) workgroups take the whole tiles of their XCD's range one after the
+// other and each issues the loads of its NEXT tile before it ranks the current one, so that a tile's HBM latency hides under the previous
+// tile's LDS work instead of under other workgroups.  Tiles are handed out by a ticket counter per XCD (tickets[x], zero at launch): the tiles
+// in flight on an XCD stay neighbours, as under the hardware's own dispatch order — with a fixed stride per workgroup they drift apart and the
+// partial sectors of neighbouring tiles no longer meet in the L2 (measured: 0.89 -> 1.44 ms per launch).  A ticket is drawn one tile ahead
+// (the returning atomic's latency hides under the ranking as well) and handed to the workgroup through one LDS word.  The array's ragged tile
+// goes to workgroup 0 afterwards.
 template <typename Key, int THREADS, int KPT, bool PAYLOAD, bool PACKED32 = false>
 __global__ __launch_bounds__(THREADS, 2) void reorder8_stay_kernel(
     const Key* __restrict__ in, Key* __restrict__ out, const uint32_t* __restrict__ pin, uint32_t* __restrict__ pout,
     const uint32_t* __restrict__ table8, const uint32_t* __restrict__ gsum8, const uint32_t* __restrict__ cbase8,
-    uint32_t chunk_groups, uint64_t n, uint32_t ntiles, uint32_t tiles_per_xcd, int remap, int shift, Key flip)
+    uint32_t chunk_groups, uint64_t n, uint32_t ntiles, uint32_t tiles_per_xcd, int remap, int shift, Key flip, uint32_t* __restrict__ tickets)
 {
+    using L = Reorder8Layout<Key, THREADS, KPT>;
     static_assert(!PACKED32 || (sizeof(Key) == 8 && !PAYLOAD), "packed (uint32 key, payload) elements are 64-bit and carry their payload themselves");
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     if (!lds_base_is_zero(smem)) {
         __builtin_trap();           // lds_store_at addresses the image from LDS address 0
     }
-    // positions p = first, first + stride, ... < range; position p of XCD x is tile x * range + (p + x * phase) mod range (tile_of_block's order)
+    constexpr int TILE = THREADS * KPT;
+    uint32_t* slot = smem + L::XBUF_DW + L::CNT_DW + 12;      // (a word of the wave-total area that the block scan does not use)
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nfull = static_cast<uint32_t>(n / TILE);
     const bool by_xcd = (remap & 1) != 0;
     const uint32_t x = by_xcd ? blockIdx.x % kNumXcd : 0u;
+    const uint32_t first = by_xcd ? x * tiles_per_xcd : 0u;
     const uint32_t range = by_xcd ? tiles_per_xcd : ntiles;
-    const uint32_t stride = by_xcd ? gridDim.x / kNumXcd : gridDim.x;
-    const uint32_t phase = by_xcd ? x * (static_cast<uint32_t>(remap) >> 8) : 0u;          // host keeps 7 * phase < tiles_per_xcd
-    const auto tile_at = [&](uint32_t p) {
-        uint32_t j = p + phase;
-        j = j >= range ? j - range : j;
-        return x * range + j;
-    };
-    const auto next_position = [&](uint32_t p) {         // (only the last XCD's range reaches past ntiles)
-        while (p < range && tile_at(p) >= ntiles) {
-            p += stride;
+    const uint32_t count = nfull <= first ? 0u : (nfull - first < range ? nfull - first : range);        // whole tiles of this XCD's range
+    const uint32_t phase = by_xcd ? x * (static_cast<uint32_t>(remap) >> 8) : 0u;
+    const auto tile_at = [&](uint32_t q) { return first + (q + phase) % count; };          // ticket q < count
+    uint32_t ticket = 0;
+    const auto draw = [&]() {
+        if (tid == 0) {
+            // (an increment, not an add: the compiler's atomic optimizer rewrites a uniform-address add into add + readfirstlane and would wait for it here)
+            ticket = __builtin_amdgcn_atomic_inc32(tickets + x, 0xffffffffu, __ATOMIC_RELAXED, "agent");
         }
-        return p;
     };
-    uint32_t p = next_position(by_xcd ? blockIdx.x / kNumXcd : blockIdx.x);
-    if (p >= range) {
-        return;
+    const auto hand_over = [&]() {          // (callers keep a barrier between the last read of the word and this)
+        if (tid == 0) {
+            *slot = ticket;
+        }
+        __syncthreads();
+        return *slot;
+    };
+    if (count != 0) {
+        draw();
+        const uint32_t q0 = hand_over();
+        if (q0 < count) {
+            Reorder8Regs<Key, KPT, PAYLOAD> cur;
+            reorder8_fetch<Key, THREADS, KPT, PAYLOAD, PACKED32, true>(cur, in, pin, table8, gsum8, cbase8, chunk_groups, n, tile_at(q0), flip);
+            draw();
+            __syncthreads();
+            uint32_t qn = hand_over();
+            for (;;) {
+                const bool more = qn < count;
+                Reorder8Regs<Key, KPT, PAYLOAD> nxt;
+                // (past the end: the range's first tile once more, never used)
+                reorder8_fetch<Key, THREADS, KPT, PAYLOAD, PACKED32, true>(nxt, in, pin, table8, gsum8, cbase8, chunk_groups, n, more ? tile_at(qn) : first, flip);
+                if (more) {
+                    draw();
+                }
+                reorder8_sort_tile<Key, THREADS, KPT, PAYLOAD, PACKED32, true>(cur, smem, out, pout, shift, flip);
+                if (!more) {
+                    break;
+                }
+                qn = hand_over();
+                cur = nxt;
+            }
+        }
     }
-    Reorder8Regs<Key, KPT, PAYLOAD> cur;
-    reorder8_fetch<Key, THREADS, KPT, PAYLOAD, PACKED32>(cur, in, pin, table8, gsum8, cbase8, chunk_groups, n, tile_at(p), flip);
-    for (;;) {
-        const uint32_t pn = next_position(p + stride);
-        const bool more = pn < range;
-        Reorder8Regs<Key, KPT, PAYLOAD> nxt;
-        if (more) {
-            reorder8_fetch<Key, THREADS, KPT, PAYLOAD, PACKED32>(nxt, in, pin, table8, gsum8, cbase8, chunk_groups, n, tile_at(pn), flip);
-        }
-        reorder8_sort_tile<Key, THREADS, KPT, PAYLOAD, PACKED32>(cur, smem, out, pout, shift, flip);
-        if (!more) {
-            break;
-        }
-        cur = nxt;
-        p = pn;
+    if (blockIdx.x == 0 && nfull < ntiles) {
+        Reorder8Regs<Key, KPT, PAYLOAD> last;
+        reorder8_fetch<Key, THREADS, KPT, PAYLOAD, PACKED32>(last, in, pin, table8, gsum8, cbase8, chunk_groups, n, nfull, flip);
+        reorder8_sort_tile<Key, THREADS, KPT, PAYLOAD, PACKED32>(last, smem, out, pout, shift, flip);
     }
 }
 

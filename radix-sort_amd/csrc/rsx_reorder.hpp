@@ -280,11 +280,13 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
     unsigned long long* peer_k = reinterpret_cast<unsigned long long*>(self_part);
     unsigned long long* peer_p = peer_k + kRadix;
     static_assert(((THREADS / kWave) * 2 * kRadix + kRadix) * 4 >= 2 * kRadix * 8, "the peer address tables fit the self-scan scratch");
+    // (loaded here, put into LDS after the key loads have been issued — written at once, the wave would wait for these before it loads its keys)
+    unsigned long long peer_k_mine = 0, peer_p_mine = 0;
     if constexpr (RANGED) {
         if (to_peers && tid < static_cast<uint32_t>(kRadix)) {
-            peer_k[tid] = peer.keys[tid];
+            peer_k_mine = peer.keys[tid];
             if constexpr (PAYLOAD) {
-                peer_p[tid] = peer.pays[tid];
+                peer_p_mine = peer.pays[tid];
             }
         }
     }
@@ -340,7 +342,9 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
     constexpr uint32_t RAKE_STRIDE = THREADS / 8;
     const bool rake_head = (tid % RAKE_STRIDE) == 0;
     const uint32_t hl = tid / RAKE_STRIDE;
-    uint32_t first_lo = 0, first_hi = 0;
+    // (the pieces of the two table entries stay apart until phase 3 adds them up: summed here, inside the raking threads' branch, the adds and with them
+    // the wait for these loads would stand BEFORE the key loads of the wave)
+    uint32_t first_lo = 0, first_hi = 0, group_lo = 0, group_hi = 0, bucket_lo = 0, bucket_hi = 0;
 #ifndef RSX_SELF_SCAN_KERNEL
 #define RSX_SELF_SCAN_KERNEL 1
 #endif
@@ -353,16 +357,16 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
         if constexpr (RANGED) {
             if (to_peers) {
                 // index inside the bucket instead of the global slot (table[b][0] = the bucket's first slot)
-                first_lo -= table[static_cast<uint64_t>(hl) * ntiles];
-                first_hi -= table[static_cast<uint64_t>(hl + 8) * ntiles];
+                bucket_lo = table[static_cast<uint64_t>(hl) * ntiles];
+                bucket_hi = table[static_cast<uint64_t>(hl + 8) * ntiles];
             }
         }
         if (globsum) {
             // PasteHistogram folded in: the table holds block-local prefixes, add the scanned
             // sum of the scan group (256 tiles of one digit) each entry lives in (RadixSort.cl:185-197)
             const uint32_t ngroups = (ntiles + kScanTiles - 1) / kScanTiles;
-            first_lo += globsum[static_cast<uint64_t>(hl) * ngroups + tile / kScanTiles];
-            first_hi += globsum[static_cast<uint64_t>(hl + 8) * ngroups + tile / kScanTiles];
+            group_lo = globsum[static_cast<uint64_t>(hl) * ngroups + tile / kScanTiles];
+            group_hi = globsum[static_cast<uint64_t>(hl + 8) * ngroups + tile / kScanTiles];
         }
     }
 
@@ -405,6 +409,14 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
         }
     }
 
+    if constexpr (RANGED) {
+        if (to_peers && tid < static_cast<uint32_t>(kRadix)) {
+            peer_k[tid] = peer_k_mine;
+            if constexpr (PAYLOAD) {
+                peer_p[tid] = peer_p_mine;
+            }
+        }
+    }
     if (self_scan) {
         // (the key loads above are in flight; this is L2-resident table work under their latency)
         // thread (q = tid & 3, r = tid >> 2) reads digits 4q..4q+3 of the rows r, r + 64, ... with 16-byte loads: a wave covers
@@ -599,6 +611,8 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
         if (rake_head) {
             // `run` is the scanned word of (true digit hl | hl+8, thread 0): the tile-local slot of the
             // tile's first key with that digit.  Stored where phase 5 looks it up: at the RAW digit.
+            first_lo += group_lo - bucket_lo;
+            first_hi += group_hi - bucket_hi;
             const uint32_t g_lo = first_lo - (run & 0xFFFFu), g_hi = first_hi - (run >> 16);
             const uint32_t r_lo = hl ^ flip_cur, r_hi = (hl + 8u) ^ flip_cur;
             runs[r_lo] = RunBase{g_lo, (r_lo << 5) - ((first_lo >> L::TILE_SHIFT) << 4)};

@@ -10,15 +10,15 @@ run() { # label, env..., -- bench args
 echo "== 8-bit scatter: RSX_R8_STAY = workgroups per CU of the staying grid (0 = one workgroup per tile), RSX_R8_EXTRA_LDS_KB left to the policy unless named"
 for v in "u32pay --payload" "u64 --dtype uint64 --dataset RandomDistributed" "u64pay --dtype uint64 --dataset RandomDistributed --payload" "u32"; do
   set -- $v; tag=$1; shift
-  for stay in 0 2 3 4 0 2; do
+  for stay in 0 2 3 0 2; do
     echo "[$tag] stay=$stay  $(RSX_R8_STAY=$stay run "$@")"
   done
 done
 echo "== staying grid with LDS that allows more workgroups per CU (extra 0) — does the prefetch stand in for occupancy?"
 for v in "u32pay --payload" "u64 --dtype uint64 --dataset RandomDistributed" "u32"; do
   set -- $v; tag=$1; shift
-  for stay in 3 4 5; do
+  for stay in 3 4; do
     echo "[$tag] extra=0 stay=$stay  $(RSX_R8_EXTRA_LDS_KB=0 RSX_R8_STAY=$stay run "$@")"
   done
 done
-} 2>&1 | tee $O/ab_stay.txt
+} 2>&1 | tee $O/ab_stay_tickets.txt
