@@ -47,6 +47,7 @@ for it in range(iters):
     e.set_option(m.OPT_INLINE_SCAN_MAX_GROUPS, (64, 2, 512)[rng.integers(0, 3)])
     e.set_option(m.OPT_FUSED_SCAN_MAX_GROUPS, (-1, 1, 0)[rng.integers(0, 3)])
     e.set_option(m.OPT_REORDER8_KERNEL, int(rng.integers(1, 4)))
+    e.set_option(m.OPT_REORDER8_STAY, (0, 0, 1, 2)[rng.integers(0, 4)])
     perm = np.arange(n, dtype=np.uint32) if payload else None
     e.upload(keys, perm)
     e.sort()
