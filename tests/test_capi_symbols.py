@@ -42,6 +42,16 @@ def test_status_enum_matches_operation_status(rsx):
         "PROGRAM_CREATION_FAILED", "NO_SOURCE_FOUND", "LOADING_SOURCE_FAILED"]
 
 
+def test_option_constants_match_the_header(rsx):
+    """every RSX_OPT_* of include/radixsort_hip.h has its OPT_* twin in the binding with the same value, and no value is used twice"""
+    text = open(HEADER).read()
+    opts = {n: int(v) for n, v in re.findall(r"RSX_OPT_([A-Z0-9_]+)\s*=\s*(\d+)", text)}
+    assert len(opts) >= 21 and len(set(opts.values())) == len(opts)
+    for name, value in opts.items():
+        assert getattr(rsx, "OPT_" + name) == value, name
+    assert {n[4:] for n in dir(rsx) if n.startswith("OPT_")} == set(opts)
+
+
 def test_library_is_gfx950_code_object(rsx):
     out = subprocess.run(["strings", "-n", "6", rsx.LIB_PATH], capture_output=True, text=True, check=True).stdout
     assert "gfx950" in out
