@@ -673,7 +673,9 @@ size_t r8_extra_lds_for(const rsx_engine* e, bool elem64, bool separate_payload)
     // uint64 keys / packed uint32 key + payload: 45 KiB + 8 = two workgroups per CU (+10 % / +27 % on random keys, +15 % on Range), and the spread between
     // engines of one process — the "modes" of rounds 1-2 — shrinks from 7-11 % to 2 % (profiles/r03_modes_vs_workgroups_per_cu.txt).  uint64 keys with a payload
     // array likewise (six engines: 14.9-16.6 ms per sort at three, 14.4-14.8 at two), at the price of 9 % on constant data, which has nothing to merge
-    return separate_payload ? (16u << 10) : (8u << 10);
+    // (keys and payloads in one image, RSX_R8_MERGED_PAYLOAD: 62 KiB per workgroup = two per CU as it stands)
+    if (separate_payload) return RSX_R8_MERGED_PAYLOAD && !RSX_R8_PADDED_FINAL ? 0u : (16u << 10);
+    return 8u << 10;
 }
 
 constexpr size_t kTickets8Bytes = 8 * rsx::kNumXcd * sizeof(uint32_t);           // at most 8 byte passes (64-bit keys)
@@ -705,12 +707,13 @@ int ensure_radix8(rsx_engine* e)
     if (!e->tickets8) RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->tickets8), kTickets8Bytes), RSX_INITIALIZATION_FAILED);
     RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L::BYTES) + extra), RSX_INITIALIZATION_FAILED);
+    using LP = rsx::Reorder8Layout<Key, kTileThreads, kKeysPerThread, true>;          // with a separate payload array: keys and payloads share the image
     RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L::BYTES) + extra), RSX_INITIALIZATION_FAILED);
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(LP::BYTES) + extra), RSX_INITIALIZATION_FAILED);
     RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8_stay_kernel<Key, kTileThreads, kKeysPerThread, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L::BYTES) + extra), RSX_INITIALIZATION_FAILED);
     RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8_stay_kernel<Key, kTileThreads, kKeysPerThread, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L::BYTES) + extra), RSX_INITIALIZATION_FAILED);
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(LP::BYTES) + extra), RSX_INITIALIZATION_FAILED);
     constexpr int lds_v2k = static_cast<int>(rsx::Reorder8V2Layout<Key, kTileThreads, kKeysPerThread, false>::BYTES);
     constexpr int lds_v2p = static_cast<int>(rsx::Reorder8V2Layout<Key, kTileThreads, kKeysPerThread, true>::BYTES);
     RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8v2_kernel<Key, kTileThreads, kKeysPerThread, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_v2k),
@@ -840,7 +843,7 @@ int sort8_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext
                                            count, g.ntiles, g.tiles_per_xcd, g.remap, shift, static_cast<uint64_t>(flip));
                     }
                 } else if (e->has_payload) {
-                    const size_t lds = L::BYTES + r8_extra_lds_for(e, sizeof(Key) == 8, true);
+                    const size_t lds = rsx::Reorder8Layout<Key, kTileThreads, kKeysPerThread, true>::BYTES + r8_extra_lds_for(e, sizeof(Key) == 8, true);
                     if (use_stay) {
                         hipLaunchKernelGGL((rsx::reorder8_stay_kernel<Key, kTileThreads, kKeysPerThread, true>), grid, dim3(kTileThreads), lds, e->stream,
                                            static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->table8, e->gsum8, e->cbase8, chunk_groups,

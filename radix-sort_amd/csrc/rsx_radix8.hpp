@@ -210,10 +210,20 @@ __global__ __launch_bounds__(kRadix8) void scan8_chunks_kernel(uint32_t* __restr
     }
 }
 
-template <typename Key, int THREADS, int KPT>
+#ifndef RSX_R8_MERGED_PAYLOAD
+#define RSX_R8_MERGED_PAYLOAD 0     // 1: a separate payload array rides in the SAME LDS image as its keys (rows of 16 keys + their 16 payloads): one trip and two barriers per round instead of two
+                                   // and four.  Measured (profiles/r03_ab_merged_payload.txt): uint64 + payload 1.31 -> 1.40 ms per launch on random keys, 1.114 -> 1.085 on constant, 1.187 -> 1.169 on
+                                   // Range; uint32 with the payload kept apart (RSX_R8_PACKED=0) 1.45 -> 1.11 (the packed default: 0.87).  Off: the random row decides.
+#endif
+#ifndef RSX_R8_PADDED_FINAL
+#define RSX_R8_PADDED_FINAL 0      // 1: the second round stages into reorder_kernel's padded image (slot + slot >> PADSH) instead of 16-key rows; both rounds unrolled
+#endif
+template <typename Key, int THREADS, int KPT, bool PAYLOAD = false>
 struct Reorder8Layout {
     static constexpr int KD = sizeof(Key) / 4;
-    static constexpr int ROW_DW = KPT * KD + 4;                 // as TileSortLayout: 16-byte aligned rows on distinct bank quads
+    static constexpr bool MERGED = PAYLOAD && RSX_R8_MERGED_PAYLOAD && !RSX_R8_PADDED_FINAL;
+    static constexpr int PAY_AT = KPT * KD;                     // dword of a row where its payloads start (MERGED)
+    static constexpr int ROW_DW = KPT * KD + (MERGED ? KPT : 0) + 4;      // as TileSortLayout: 16-byte aligned rows on distinct bank quads
     static constexpr int XBUF_DW = THREADS * ROW_DW;
     static constexpr int CNT_DW = 8 * THREADS;
     static constexpr int TOTAL_DW = XBUF_DW + CNT_DW + 16 + kRadix8;
@@ -324,7 +334,8 @@ __device__ __forceinline__ void reorder8_fetch(Reorder8Regs<Key, KPT, PAYLOAD>& 
 template <typename Key, int THREADS, int KPT, bool PAYLOAD, bool PACKED32, bool UNROLL_ROUNDS = false>
 __device__ __forceinline__ void reorder8_sort_tile(Reorder8Regs<Key, KPT, PAYLOAD>& t, uint32_t* smem, Key* __restrict__ out, uint32_t* __restrict__ pout, int shift, Key flip)
 {
-    using L = Reorder8Layout<Key, THREADS, KPT>;
+    using L = Reorder8Layout<Key, THREADS, KPT, PAYLOAD>;
+    constexpr bool MERGED = L::MERGED;
     constexpr int TILE = THREADS * KPT;
     constexpr int KD = L::KD;
     constexpr int VEC = KeyVec<Key>::N;
@@ -351,13 +362,10 @@ __device__ __forceinline__ void reorder8_sort_tile(Reorder8Regs<Key, KPT, PAYLOA
 
     u32_alias* cnt32 = reinterpret_cast<u32_alias*>(cnt);
     unsigned char* cbytes = reinterpret_cast<unsigned char*>(cnt);
-    // image: slot s at dword s*KD + 4*(s/16) (rows of KPT keys + 16 bytes); slot i = r*THREADS + tid -> per-thread base + r * OUT_STRIDE
-    constexpr uint32_t OUT_STRIDE_DW = THREADS * KD + (THREADS / 16) * 4;
-    const uint32_t out_base_dw = tid * KD + ((tid >> 4) << 2);
+    // image: slot s in row s/16 (KPT keys [+ their KPT payloads when MERGED] + 16 bytes) at key j = s%16; slot i = r*THREADS + tid -> per-thread base + r * OUT_STRIDE
+    constexpr uint32_t OUT_STRIDE_DW = (THREADS / 16) * L::ROW_DW;
+    const uint32_t out_base_dw = (tid >> 4) * L::ROW_DW + (tid & 15u) * KD;
 
-#ifndef RSX_R8_PADDED_FINAL
-#define RSX_R8_PADDED_FINAL 0      // 1: the second round stages into reorder_kernel's padded image (slot + slot >> PADSH) instead of 16-key rows; both rounds unrolled
-#endif
     constexpr int PADSH = (KD == 1) ? 5 : 4;
     constexpr int kRoundsUnrolled = (RSX_R8_PADDED_FINAL || UNROLL_ROUNDS) ? 2 : 1;
 #pragma unroll kRoundsUnrolled
@@ -425,6 +433,10 @@ __device__ __forceinline__ void reorder8_sort_tile(Reorder8Regs<Key, KPT, PAYLOA
                 // byte offset of slot s: (s*KD + 4*(s>>4)) * 4
                 if (padded) {
                     lds_store_at<Key>(add_lshl<(KD == 1 ? 2 : 3)>(slot[i], slot[i] >> PADSH), t.k[i]);
+                } else if constexpr (MERGED) {
+                    const uint32_t row_at = (slot[i] >> 4) * static_cast<uint32_t>(L::ROW_DW * 4), j4 = (slot[i] & 15u) << 2;
+                    lds_store_at<Key>(row_at + j4 * KD, t.k[i]);
+                    lds_store_at<uint32_t>(row_at + j4 + static_cast<uint32_t>(L::PAY_AT * 4), t.pl[i]);
                 } else if constexpr (KD == 1) {
                     lds_store_at<Key>(add_lshl<2>(slot[i], (slot[i] >> 2) & ~3u), t.k[i]);
                 } else {
@@ -442,6 +454,16 @@ __device__ __forceinline__ void reorder8_sort_tile(Reorder8Regs<Key, KPT, PAYLOA
                     t.k[j * VEC + e] = v.k[e];
                 }
             }
+            if constexpr (MERGED) {
+#pragma unroll
+                for (int q = 0; q < KPT / 4; ++q) {
+                    const U32x4 x = *reinterpret_cast<const U32x4*>(xbuf + tid * L::ROW_DW + L::PAY_AT + q * 4);
+                    t.pl[q * 4 + 0] = x.v[0];
+                    t.pl[q * 4 + 1] = x.v[1];
+                    t.pl[q * 4 + 2] = x.v[2];
+                    t.pl[q * 4 + 3] = x.v[3];
+                }
+            }
         } else {
             // leave as runs: slot i = r*THREADS + tid, its global slot = gb[digit] + i
             Key okey[KPT];
@@ -451,6 +473,13 @@ __device__ __forceinline__ void reorder8_sort_tile(Reorder8Regs<Key, KPT, PAYLOA
                     okey[r] = reinterpret_cast<const Key*>(xbuf)[tid + (tid >> PADSH) + static_cast<uint32_t>(r) * (THREADS + (THREADS >> PADSH))];
                 } else {
                     okey[r] = *reinterpret_cast<const Key*>(xbuf + out_base_dw + static_cast<uint32_t>(r) * OUT_STRIDE_DW);
+                }
+            }
+            uint32_t opay[MERGED ? KPT : 1];
+            if constexpr (MERGED) {
+#pragma unroll
+                for (int r = 0; r < KPT; ++r) {
+                    opay[r] = xbuf[(tid >> 4) * L::ROW_DW + L::PAY_AT + (tid & 15u) + static_cast<uint32_t>(r) * OUT_STRIDE_DW];
                 }
             }
             uint32_t g[KPT];
@@ -490,14 +519,21 @@ __device__ __forceinline__ void reorder8_sort_tile(Reorder8Regs<Key, KPT, PAYLOA
                     }
                 }
             }
-            if constexpr (PAYLOAD) {
+            if constexpr (MERGED) {
+#pragma unroll
+                for (int r = 0; r < KPT; ++r) {
+                    if (full || static_cast<uint32_t>(r) * THREADS + tid < valid) {
+                        pout[g[r]] = opay[r];
+                    }
+                }
+            } else if constexpr (PAYLOAD) {
 #pragma unroll
                 for (int r = 0; r < KPT; ++r) {
                     t.k[r] = static_cast<Key>(g[r]);          // keys are gone; keep each slot's destination for its payload
                 }
             }
         }
-        if constexpr (PAYLOAD) {
+        if constexpr (PAYLOAD && !MERGED) {
             __syncthreads();           // every thread has taken its keys: the image carries the payload now
 #pragma unroll
             for (int i = 0; i < KPT; ++i) {

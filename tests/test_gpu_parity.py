@@ -513,6 +513,26 @@ def test_8bit_digits_full_size_2pow28_bit_exact_vs_oracle(mod, oracle):
     assert np.array_equal(got, oracle.radix_sort(keys))
 
 
+@pytest.mark.parametrize("dt,kind", [("uint64", "SeededUniform"), ("uint32", "Random"), ("int64", "Zeros")])
+def test_8bit_digits_full_size_2pow28_with_payload(mod, oracle, dt, kind):
+    """The payload rows of the 8-bit workload matrix at their real size (BASELINE config 3's shape and the packed uint32 + payload
+    scatter): ascending, a permutation of the input, the payload followed its key, equal keys keep their input order."""
+    n = 1 << 28
+    keys = oracle.dataset(kind, dt, n)
+    with mod.Engine(dt, n, payload=True) as e:
+        e.set_option(mod.OPT_RADIX_BITS, 8)
+        e.upload(keys, np.arange(n, dtype=np.uint32))
+        e.sort()
+        ks, ps = e.download(want_perm=True)
+    assert bool(np.all(ks[:-1] <= ks[1:]))
+    assert _checksums(ks) == _checksums(keys)
+    assert np.array_equal(keys[ps], ks)
+    ties = np.flatnonzero(ks[:-1] == ks[1:])
+    assert bool(np.all(ps[ties] < ps[ties + 1]))
+    if kind == "Zeros":
+        assert np.array_equal(ps, np.arange(n, dtype=np.uint32))
+
+
 # --------------------------------------------------------------------------- table scan variants
 @pytest.mark.parametrize("dt,payload", [("uint32", False), ("int64", True)])
 @pytest.mark.parametrize("n", [5000, 300001, (1 << 22) + 17, (1 << 24) + 4097])
