@@ -210,6 +210,9 @@ __global__ __launch_bounds__(kRadix8) void scan8_chunks_kernel(uint32_t* __restr
     }
 }
 
+#ifndef RSX_R8_PACKED_SPLIT_STORES
+#define RSX_R8_PACKED_SPLIT_STORES 0
+#endif
 #ifndef RSX_R8_MERGED_PAYLOAD
 #define RSX_R8_MERGED_PAYLOAD 0     // 1: a separate payload array rides in the SAME LDS image as its keys (rows of 16 keys + their 16 payloads): one trip and two barriers per round instead of two
                                    // and four.  Measured (profiles/r03_ab_merged_payload.txt): uint64 + payload 1.31 -> 1.40 ms per launch on random keys, 1.114 -> 1.085 on constant, 1.187 -> 1.169 on
@@ -499,6 +502,20 @@ __device__ __forceinline__ void reorder8_sort_tile(Reorder8Regs<Key, KPT, PAYLOA
             }
             if constexpr (PACKED32) {
                 uint32_t* out32 = reinterpret_cast<uint32_t*>(out);
+#if RSX_R8_PACKED_SPLIT_STORES          // experiment: all key stores, then all payload stores (default: key and payload of a slot together)
+#pragma unroll
+                for (int r = 0; r < KPT; ++r) {
+                    if (full || static_cast<uint32_t>(r) * THREADS + tid < valid) {
+                        out32[g[r]] = static_cast<uint32_t>(okey[r]);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < KPT; ++r) {
+                    if (full || static_cast<uint32_t>(r) * THREADS + tid < valid) {
+                        pout[g[r]] = static_cast<uint32_t>(okey[r] >> 32);
+                    }
+                }
+#else
 #pragma unroll
                 for (int r = 0; r < KPT; ++r) {
                     if (full || static_cast<uint32_t>(r) * THREADS + tid < valid) {
@@ -506,27 +523,27 @@ __device__ __forceinline__ void reorder8_sort_tile(Reorder8Regs<Key, KPT, PAYLOA
                         pout[g[r]] = static_cast<uint32_t>(okey[r] >> 32);
                     }
                 }
+#endif
             } else if (full) {
 #pragma unroll
                 for (int r = 0; r < KPT; ++r) {
                     out[g[r]] = okey[r];
+                    if constexpr (MERGED) {
+                        pout[g[r]] = opay[r];          // (key and payload of a slot together: all keys first, then all payloads, is 7 % slower — r03_ab_split_stores.txt)
+                    }
                 }
             } else {
 #pragma unroll
                 for (int r = 0; r < KPT; ++r) {
                     if (static_cast<uint32_t>(r) * THREADS + tid < valid) {
                         out[g[r]] = okey[r];
+                        if constexpr (MERGED) {
+                            pout[g[r]] = opay[r];
+                        }
                     }
                 }
             }
-            if constexpr (MERGED) {
-#pragma unroll
-                for (int r = 0; r < KPT; ++r) {
-                    if (full || static_cast<uint32_t>(r) * THREADS + tid < valid) {
-                        pout[g[r]] = opay[r];
-                    }
-                }
-            } else if constexpr (PAYLOAD) {
+            if constexpr (PAYLOAD && !MERGED) {
 #pragma unroll
                 for (int r = 0; r < KPT; ++r) {
                     t.k[r] = static_cast<Key>(g[r]);          // keys are gone; keep each slot's destination for its payload
