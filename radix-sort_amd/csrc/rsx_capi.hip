@@ -207,6 +207,8 @@ struct rsx_engine {
     long reorder_extra_lds = -1;
     // default 8-bit scatter as a grid that stays (rsx::reorder8_stay_kernel): workgroups per CU of that grid, 0 = one workgroup per tile (env RSX_R8_STAY; -1 = policy)
     int r8_stay = -1;
+    // kernel 1 on workgroups of 512 threads x 8 keys (the same 4096-key tiles, tables and LDS bytes in flight; twice the waves): env RSX_R8_WIDE, -1 = policy
+    int r8_wide = -1;
     int num_cus = 0;
     int r8_packed = 1;          // 8-bit scatter of uint32 keys WITH payload: key and payload as one 64-bit element through the ranking rounds (env RSX_R8_PACKED; kernel 1 only)
     int lds_atomics_ordered = -1;               // -1 not probed yet; 1: ds_add_rtn serves lanes in ascending lane order on this device (lds_atomic_order_probe_kernel); 0: it does not, kernel 3 is refused
@@ -680,6 +682,16 @@ size_t r8_extra_lds_for(const rsx_engine* e, bool elem64, bool separate_payload)
 
 constexpr size_t kTickets8Bytes = 8 * rsx::kNumXcd * sizeof(uint32_t);           // at most 8 byte passes (64-bit keys)
 
+// 512-thread workgroups for the default 8-bit scatter, by variant
+bool r8_wide_for(const rsx_engine* e, bool key64, bool has_payload)
+{
+    if (e->r8_wide >= 0) return e->r8_wide != 0;
+    // 64-bit keys without payload run at two waves per SIMD on 256-thread tiles (two workgroups per CU is all the L2 takes, r8_extra_lds_for) and wait: twice the waves
+    // on the same bytes in flight, 0.896 -> 0.807 ms per launch on uniform keys, 0.776 -> 0.720 on constant ones.  Every other variant loses 2-12 % to the doubled
+    // per-thread overhead (counter words, raking scan; 8-wave barriers): profiles/r03_ab_wide.txt
+    return key64 && !has_payload;
+}
+
 // workgroups per CU of the staying grid of the default 8-bit scatter (0 = one workgroup per tile), by variant
 int r8_stay_for(const rsx_engine* e, bool elem64, bool separate_payload)
 {
@@ -714,6 +726,19 @@ int ensure_radix8(rsx_engine* e)
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L::BYTES) + extra), RSX_INITIALIZATION_FAILED);
     RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8_stay_kernel<Key, kTileThreads, kKeysPerThread, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(LP::BYTES) + extra), RSX_INITIALIZATION_FAILED);
+    {
+        using WK = rsx::Reorder8Layout<Key, 512, 8, false>;
+        using WP = rsx::Reorder8Layout<Key, 512, 8, true>;
+        RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8_kernel<Key, 512, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(WK::BYTES) + extra),
+                RSX_INITIALIZATION_FAILED);
+        RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8_kernel<Key, 512, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(WP::BYTES) + extra),
+                RSX_INITIALIZATION_FAILED);
+        if constexpr (sizeof(Key) == 4) {
+            using WX = rsx::Reorder8Layout<uint64_t, 512, 8, false>;
+            RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8_kernel<uint64_t, 512, 8, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(WX::BYTES) + extra),
+                    RSX_INITIALIZATION_FAILED);
+        }
+    }
     constexpr int lds_v2k = static_cast<int>(rsx::Reorder8V2Layout<Key, kTileThreads, kKeysPerThread, false>::BYTES);
     constexpr int lds_v2p = static_cast<int>(rsx::Reorder8V2Layout<Key, kTileThreads, kKeysPerThread, true>::BYTES);
     RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8v2_kernel<Key, kTileThreads, kKeysPerThread, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_v2k),
@@ -828,12 +853,21 @@ int sort8_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext
             } else {
                 // kernel 1.  stay > 0: a grid of that many workgroups per CU walks the tiles and prefetches (reorder8_stay_kernel)
                 const bool packed = r8_packed;
+                const bool wide = !use_stay && r8_wide_for(e, sizeof(Key) == 8, e->has_payload);
+                const size_t wide_extra = e->r8_extra_lds >= 0 ? static_cast<size_t>(e->r8_extra_lds) : 0;      // (57-62 KiB per workgroup: two per CU as they stand)
+                constexpr size_t lds_wide_packed = rsx::Reorder8Layout<uint64_t, 512, 8, false>::BYTES;
+                constexpr size_t lds_wide_keys = rsx::Reorder8Layout<Key, 512, 8, false>::BYTES;
+                constexpr size_t lds_wide_pay = rsx::Reorder8Layout<Key, 512, 8, true>::BYTES;
                 const dim3 grid(use_stay ? stay_blocks : g.blocks);
                 if (packed) {
                     // uint32 key + payload as one 64-bit element (rsx::reorder8_kernel<.., PACKED32>)
                     constexpr size_t lds_packed = rsx::Reorder8Layout<uint64_t, kTileThreads, kKeysPerThread>::BYTES;
                     const size_t lds = lds_packed + r8_extra_lds_for(e, true, false);
-                    if (use_stay) {
+                    if (wide) {
+                        hipLaunchKernelGGL((rsx::reorder8_kernel<uint64_t, 512, 8, false, true>), grid, dim3(512), lds_wide_packed + wide_extra, e->stream,
+                                           static_cast<const uint64_t*>(in), static_cast<uint64_t*>(out), pin, pout, e->table8, e->gsum8, e->cbase8, chunk_groups,
+                                           count, g.ntiles, g.tiles_per_xcd, g.remap, shift, static_cast<uint64_t>(flip));
+                    } else if (use_stay) {
                         hipLaunchKernelGGL((rsx::reorder8_stay_kernel<uint64_t, kTileThreads, kKeysPerThread, false, true>), grid, dim3(kTileThreads), lds, e->stream,
                                            static_cast<const uint64_t*>(in), static_cast<uint64_t*>(out), pin, pout, e->table8, e->gsum8, e->cbase8, chunk_groups,
                                            count, g.ntiles, g.tiles_per_xcd, g.remap, shift, static_cast<uint64_t>(flip), e->tickets8 + static_cast<size_t>(pass / 2) * rsx::kNumXcd);
@@ -844,7 +878,11 @@ int sort8_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext
                     }
                 } else if (e->has_payload) {
                     const size_t lds = rsx::Reorder8Layout<Key, kTileThreads, kKeysPerThread, true>::BYTES + r8_extra_lds_for(e, sizeof(Key) == 8, true);
-                    if (use_stay) {
+                    if (wide) {
+                        hipLaunchKernelGGL((rsx::reorder8_kernel<Key, 512, 8, true>), grid, dim3(512), lds_wide_pay + wide_extra, e->stream,
+                                           static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->table8, e->gsum8, e->cbase8, chunk_groups,
+                                           count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip);
+                    } else if (use_stay) {
                         hipLaunchKernelGGL((rsx::reorder8_stay_kernel<Key, kTileThreads, kKeysPerThread, true>), grid, dim3(kTileThreads), lds, e->stream,
                                            static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->table8, e->gsum8, e->cbase8, chunk_groups,
                                            count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip, e->tickets8 + static_cast<size_t>(pass / 2) * rsx::kNumXcd);
@@ -855,7 +893,11 @@ int sort8_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext
                     }
                 } else {
                     const size_t lds = L::BYTES + r8_extra_lds_for(e, sizeof(Key) == 8, false);
-                    if (use_stay) {
+                    if (wide) {
+                        hipLaunchKernelGGL((rsx::reorder8_kernel<Key, 512, 8, false>), grid, dim3(512), lds_wide_keys + wide_extra, e->stream,
+                                           static_cast<const Key*>(in), static_cast<Key*>(out), nullptr, nullptr, e->table8, e->gsum8, e->cbase8, chunk_groups,
+                                           count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip);
+                    } else if (use_stay) {
                         hipLaunchKernelGGL((rsx::reorder8_stay_kernel<Key, kTileThreads, kKeysPerThread, false>), grid, dim3(kTileThreads), lds, e->stream,
                                            static_cast<const Key*>(in), static_cast<Key*>(out), nullptr, nullptr, e->table8, e->gsum8, e->cbase8, chunk_groups,
                                            count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip, e->tickets8 + static_cast<size_t>(pass / 2) * rsx::kNumXcd);
@@ -1355,6 +1397,7 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
     if (const char* env = std::getenv("RSX_RADIX_BITS")) e->radix_bits = std::atoi(env) == 8 ? 8 : 4;
     if (const char* env = std::getenv("RSX_REORDER_EXTRA_LDS_KB")) e->reorder_extra_lds = std::atoi(env) < 0 ? -1L : static_cast<long>(std::min(64, std::atoi(env))) * 1024;
     if (const char* env = std::getenv("RSX_R8_PACKED")) e->r8_packed = std::atoi(env) != 0;
+    if (const char* env = std::getenv("RSX_R8_WIDE")) e->r8_wide = std::max(-1, std::min(1, std::atoi(env)));
     if (const char* env = std::getenv("RSX_R8_STAY")) e->r8_stay = std::max(-1, std::min(8, std::atoi(env)));
     if (const char* env = std::getenv("RSX_R8_EXTRA_LDS_KB")) e->r8_extra_lds = std::atoi(env) < 0 ? -1L : static_cast<long>(std::min(96, std::atoi(env))) * 1024;
     if (const char* env = std::getenv("RSX_REORDER8_V")) e->reorder8_version = std::max(1, std::min(3, std::atoi(env)));

@@ -233,7 +233,9 @@ struct Reorder8Layout {
     static constexpr size_t BYTES = static_cast<size_t>(TOTAL_DW) * 4;
     static constexpr int WGS_PER_CU = static_cast<int>((160 * 1024) / BYTES);
     static constexpr int MIN_WAVES = (WGS_PER_CU * THREADS / 256) > 8 ? 8 : (WGS_PER_CU * THREADS / 256);
-    static_assert(KPT == 16 && THREADS == kRadix8, "row geometry; one thread per digit handles the tile's table row");
+    static constexpr int LG = (KPT == 16) ? 4 : 3;              // log2 of the slots per row
+    static_assert((KPT == 16 || KPT == 8) && THREADS * KPT == 4096 && THREADS >= kRadix8, "4096-key tiles in rows of KPT slots; the first 256 threads handle the tile's table row");
+    static_assert(KPT == 16 || !RSX_R8_PADDED_FINAL, "the padded second-round image is written for rows of 16");
 };
 
 // One tile's keys (and payloads) in registers as loaded — sign flip not yet applied — with this thread's entry of the tile's table row.
@@ -275,9 +277,10 @@ __device__ __forceinline__ void reorder8_fetch(Reorder8Regs<Key, KPT, PAYLOAD>& 
     // this thread's digit of the tile's table row (latency hides under the key loads): global slot of the tile's first key with
     // that digit minus its tile-local slot
     const uint32_t group = tile / kScan8Tiles;
-    t.base3[0] = table8[static_cast<uint64_t>(tile) * kRadix8 + tid];
-    t.base3[1] = gsum8[static_cast<uint64_t>(group) * kRadix8 + tid];
-    t.base3[2] = cbase8[static_cast<uint64_t>(group / chunk_groups) * kRadix8 + tid];      // smaller digits + this digit in earlier chunks
+    const uint32_t dg = (THREADS == kRadix8) ? tid : (tid & static_cast<uint32_t>(kRadix8 - 1));      // (wider workgroups: the upper threads load the same row again and do not use it)
+    t.base3[0] = table8[static_cast<uint64_t>(tile) * kRadix8 + dg];
+    t.base3[1] = gsum8[static_cast<uint64_t>(group) * kRadix8 + dg];
+    t.base3[2] = cbase8[static_cast<uint64_t>(group / chunk_groups) * kRadix8 + dg];      // smaller digits + this digit in earlier chunks
     if constexpr (PACKED32) {
         const uint32_t* in32 = reinterpret_cast<const uint32_t*>(in);
         if (full) {
@@ -361,13 +364,16 @@ __device__ __forceinline__ void reorder8_sort_tile(Reorder8Regs<Key, KPT, PAYLOA
             t.k[i] ^= flip;
         }
     }
-    gb[tid] = t.base3[0] + t.base3[1] + t.base3[2];          // (read after several barriers)
+    if (THREADS == kRadix8 || tid < static_cast<uint32_t>(kRadix8)) {
+        gb[tid] = t.base3[0] + t.base3[1] + t.base3[2];          // (read after several barriers)
+    }
 
     u32_alias* cnt32 = reinterpret_cast<u32_alias*>(cnt);
     unsigned char* cbytes = reinterpret_cast<unsigned char*>(cnt);
-    // image: slot s in row s/16 (KPT keys [+ their KPT payloads when MERGED] + 16 bytes) at key j = s%16; slot i = r*THREADS + tid -> per-thread base + r * OUT_STRIDE
-    constexpr uint32_t OUT_STRIDE_DW = (THREADS / 16) * L::ROW_DW;
-    const uint32_t out_base_dw = (tid >> 4) * L::ROW_DW + (tid & 15u) * KD;
+    // image: slot s in row s/KPT (KPT keys [+ their KPT payloads when MERGED] + 16 bytes) at key j = s%KPT; slot i = r*THREADS + tid -> per-thread base + r * OUT_STRIDE
+    constexpr int LG = L::LG;
+    constexpr uint32_t OUT_STRIDE_DW = (THREADS / KPT) * L::ROW_DW;
+    const uint32_t out_base_dw = (tid >> LG) * L::ROW_DW + (tid & static_cast<uint32_t>(KPT - 1)) * KD;
 
     constexpr int PADSH = (KD == 1) ? 5 : 4;
     constexpr int kRoundsUnrolled = (RSX_R8_PADDED_FINAL || UNROLL_ROUNDS) ? 2 : 1;
@@ -437,13 +443,13 @@ __device__ __forceinline__ void reorder8_sort_tile(Reorder8Regs<Key, KPT, PAYLOA
                 if (padded) {
                     lds_store_at<Key>(add_lshl<(KD == 1 ? 2 : 3)>(slot[i], slot[i] >> PADSH), t.k[i]);
                 } else if constexpr (MERGED) {
-                    const uint32_t row_at = (slot[i] >> 4) * static_cast<uint32_t>(L::ROW_DW * 4), j4 = (slot[i] & 15u) << 2;
+                    const uint32_t row_at = (slot[i] >> LG) * static_cast<uint32_t>(L::ROW_DW * 4), j4 = (slot[i] & static_cast<uint32_t>(KPT - 1)) << 2;
                     lds_store_at<Key>(row_at + j4 * KD, t.k[i]);
                     lds_store_at<uint32_t>(row_at + j4 + static_cast<uint32_t>(L::PAY_AT * 4), t.pl[i]);
                 } else if constexpr (KD == 1) {
-                    lds_store_at<Key>(add_lshl<2>(slot[i], (slot[i] >> 2) & ~3u), t.k[i]);
+                    lds_store_at<Key>(add_lshl<2>(slot[i], (slot[i] >> (LG - 2)) & ~3u), t.k[i]);
                 } else {
-                    lds_store_at<Key>(add_lshl<2>(slot[i] << 1, (slot[i] >> 2) & ~3u), t.k[i]);
+                    lds_store_at<Key>(add_lshl<2>(slot[i] << 1, (slot[i] >> (LG - 2)) & ~3u), t.k[i]);
                 }
             }
         }
@@ -482,7 +488,7 @@ __device__ __forceinline__ void reorder8_sort_tile(Reorder8Regs<Key, KPT, PAYLOA
             if constexpr (MERGED) {
 #pragma unroll
                 for (int r = 0; r < KPT; ++r) {
-                    opay[r] = xbuf[(tid >> 4) * L::ROW_DW + L::PAY_AT + (tid & 15u) + static_cast<uint32_t>(r) * OUT_STRIDE_DW];
+                    opay[r] = xbuf[(tid >> LG) * L::ROW_DW + L::PAY_AT + (tid & static_cast<uint32_t>(KPT - 1)) + static_cast<uint32_t>(r) * OUT_STRIDE_DW];
                 }
             }
             uint32_t g[KPT];
@@ -557,7 +563,7 @@ __device__ __forceinline__ void reorder8_sort_tile(Reorder8Regs<Key, KPT, PAYLOA
                 if (padded) {
                     lds_store_at<uint32_t>(add_lshl<2>(slot[i], slot[i] >> 5), t.pl[i]);
                 } else {
-                    lds_store_at<uint32_t>(add_lshl<2>(slot[i], (slot[i] >> 2) & ~3u), t.pl[i]);
+                    lds_store_at<uint32_t>(add_lshl<2>(slot[i], (slot[i] >> (LG - 2)) & ~3u), t.pl[i]);
                 }
             }
             __syncthreads();
@@ -571,8 +577,8 @@ __device__ __forceinline__ void reorder8_sort_tile(Reorder8Regs<Key, KPT, PAYLOA
                     t.pl[q * 4 + 3] = x.v[3];
                 }
             } else {
-                const uint32_t pbase = padded ? tid + (tid >> 5) : tid + ((tid >> 4) << 2);
-                const uint32_t pstride = padded ? THREADS + (THREADS >> 5) : THREADS + (THREADS / 16) * 4;
+                const uint32_t pbase = padded ? tid + (tid >> 5) : tid + ((tid >> LG) << 2);
+                const uint32_t pstride = padded ? THREADS + (THREADS >> 5) : THREADS + (THREADS / KPT) * 4;
 #pragma unroll
                 for (int r = 0; r < KPT; ++r) {
                     if (full || static_cast<uint32_t>(r) * THREADS + tid < valid) {
@@ -590,7 +596,7 @@ __device__ __forceinline__ void reorder8_sort_tile(Reorder8Regs<Key, KPT, PAYLOA
 // uint32 keys, `pin` / `pout` at the payloads.  One 8-byte LDS access per element and round instead of two 4-byte ones, and none of the
 // payload's own trips (4 barriers fewer per tile): the uint32 + payload scatter then costs what the uint64 keys-only one costs.
 template <typename Key, int THREADS, int KPT, bool PAYLOAD, bool PACKED32 = false>
-__global__ __launch_bounds__(THREADS, (PAYLOAD ? 2 : (Reorder8Layout<Key, THREADS, KPT>::MIN_WAVES > 4 ? 4 : Reorder8Layout<Key, THREADS, KPT>::MIN_WAVES))) void reorder8_kernel(
+__global__ __launch_bounds__(THREADS, (PAYLOAD ? (THREADS > 256 ? 4 : 2) : (Reorder8Layout<Key, THREADS, KPT>::MIN_WAVES > 4 ? 4 : Reorder8Layout<Key, THREADS, KPT>::MIN_WAVES))) void reorder8_kernel(
     const Key* __restrict__ in, Key* __restrict__ out, const uint32_t* __restrict__ pin, uint32_t* __restrict__ pout,
     const uint32_t* __restrict__ table8, const uint32_t* __restrict__ gsum8, const uint32_t* __restrict__ cbase8,
     uint32_t chunk_groups, uint64_t n, uint32_t ntiles, uint32_t tiles_per_xcd, int remap, int shift, Key flip)

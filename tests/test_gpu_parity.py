@@ -1211,3 +1211,35 @@ def test_8bit_scatter_as_a_staying_grid_is_exact(mod, oracle, dt, n, stay):
             for bad in (-2, 9):
                 with pytest.raises(mod.RadixSortError):
                     e.set_option(mod.OPT_REORDER8_STAY, bad)
+
+
+@pytest.mark.parametrize("dt,n", [("uint32", (1 << 21) + 4099), ("int32", 70001), ("uint64", (1 << 21) - 4097), ("int64", 3 * (1 << 19) + 77)])
+def test_8bit_scatter_on_512_thread_workgroups_is_exact(mod, oracle, dt, n):
+    """RSX_R8_WIDE (read at rsx_create; -1 = the policy: 512 threads for 64-bit keys without payload): kernel 1 of the 8-bit passes on workgroups of
+    512 threads x 8 keys — the same 4096-key tiles and tables, rows of 8 slots in the LDS image — and on 256 x 16 give the same keys and the same
+    stable payload order; keys only, payload (packed for 32-bit keys), payload kept apart, ragged last tile, ties, constant data."""
+    import os
+    keys = oracle.dataset("SeededUniform", dt, n, seed=n % 19)
+    keys[::4] = keys[5]
+    for data in (keys, np.full(n, keys[9], dtype=dt)):
+        want_k = np.sort(data)
+        want_p = np.argsort(data, kind="stable").astype(np.uint32)
+        for payload, packed, wide in [(False, "1", "1"), (False, "1", "0"), (True, "1", "1")] + ([(True, "0", "1")] if np.dtype(dt).itemsize == 4 else []):
+            os.environ["RSX_R8_PACKED"] = packed
+            os.environ["RSX_R8_WIDE"] = wide
+            try:
+                e = mod.Engine(dt, n, payload=payload)
+            finally:
+                del os.environ["RSX_R8_PACKED"], os.environ["RSX_R8_WIDE"]
+            with e:
+                e.set_option(mod.OPT_RADIX_BITS, 8)
+                if payload:
+                    e.upload(data, np.arange(n, dtype=np.uint32))
+                    e.sort()
+                    ks, ps = e.download(want_perm=True)
+                    assert np.array_equal(ps, want_p)
+                else:
+                    e.upload(data)
+                    e.sort()
+                    ks = e.download()
+                assert np.array_equal(ks, want_k)
