@@ -56,6 +56,8 @@ constexpr int kTileThreads = RSX_TILE_THREADS;
 constexpr int kKeysPerThread = RSX_KPT;
 constexpr int kTileKeys = kTileThreads * kKeysPerThread;
 constexpr int kSmallKeysPerThread = 4;      // small self-scan sorts: tiles of 1024 keys
+// (probe builds with another tile shape, e.g. -DRSX_TILE_THREADS=512 -DRSX_KPT=8, leave out the one-launch tile sort, the inline scan and the 8-bit chain, which are written for 256 x 16)
+#define RSX_PRODUCT_SHAPE (RSX_TILE_THREADS == 256 && RSX_KPT == 16)
 
 enum Phase : int { PH_HISTO = 0, PH_SCAN = 1, PH_PASTE = 2, PH_REORDER = 3, PH_TOTAL = 4, PH_COUNT = 5 };
 
@@ -205,6 +207,7 @@ struct rsx_engine {
     // fewer workgroups per CU (three instead of four: six engines 6.26-6.84 -> 6.17-6.55 ms per sort); uint32 keys, uint64 keys and uint64 + payload lose 1-20 %
     // (profiles/r03_4bit_workgroups_per_cu.txt, r03_modes_u32pay4_workgroups_per_cu.txt)
     long reorder_extra_lds = -1;
+    int reorder_wide = -1;      // 4-bit reorder of 64-bit keys WITH payload on 512 threads x 8 keys (env RSX_REORDER_WIDE: 0 / 1, -1 = policy: on)
     // default 8-bit scatter as a grid that stays (rsx::reorder8_stay_kernel): workgroups per CU of that grid, 0 = one workgroup per tile (env RSX_R8_STAY; -1 = policy)
     int r8_stay = -1;
     // kernel 1 on workgroups of 512 threads x 8 keys (the same 4096-key tiles, tables and LDS bytes in flight; twice the waves): env RSX_R8_WIDE, -1 = policy
@@ -458,18 +461,18 @@ int launch_paste(rsx_engine* e, uint64_t count)
 // OUTPUT tile into e->counts_next (all zero on entry: zeroed at the start of the sort and handed
 // back zeroed by the scan that consumes it).  fold_paste: the table holds block-local prefixes
 // and the kernel adds the scanned block sums itself (no paste launch).
-template <typename Key, bool PAYLOAD, bool LOOKAHEAD, bool RANGED = false, int KPT = kKeysPerThread>
+template <typename Key, bool PAYLOAD, bool LOOKAHEAD, bool RANGED = false, int KPT = kKeysPerThread, int THREADS = kTileThreads>
 int launch_reorder_t(rsx_engine* e, const void* in, void* out, const uint32_t* pin, uint32_t* pout, uint64_t count, int shift,
                      uint32_t mask, int next_shift, bool fold_paste, Key lo = Key{0}, Key mul = Key{0}, uint32_t nsplit = 0,
                      rsx::SelfScanArgs self = rsx::SelfScanArgs{nullptr, nullptr, nullptr}, uint32_t* next_counts = nullptr,
                      rsx::PeerArgs peer = rsx::PeerArgs{nullptr, nullptr})
 {
-    using L = rsx::ReorderLayout<Key, kTileThreads, KPT, (!RANGED && RSX_ALIAS_COUNTERS != 0)>;
-    const Grid g = grid_for(e, count, kTileThreads * KPT);
+    using L = rsx::ReorderLayout<Key, THREADS, KPT, (!RANGED && RSX_ALIAS_COUNTERS != 0)>;
+    const Grid g = grid_for(e, count, THREADS * KPT);
     e->last_in = in;
     e->last_shift = shift;
     Bracket b(e, PH_REORDER);
-    hipLaunchKernelGGL((rsx::reorder_kernel<Key, kTileThreads, KPT, PAYLOAD, LOOKAHEAD, RANGED>), dim3(g.blocks), dim3(kTileThreads),
+    hipLaunchKernelGGL((rsx::reorder_kernel<Key, THREADS, KPT, PAYLOAD, LOOKAHEAD, RANGED>), dim3(g.blocks), dim3(THREADS),
                        L::BYTES + (KPT != kKeysPerThread ? 0u : e->reorder_extra_lds >= 0 ? static_cast<size_t>(e->reorder_extra_lds) : (PAYLOAD && sizeof(Key) == 4 && !RANGED) ? (16u << 10) : 0u),
                        e->stream, static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->table, count,
                        g.ntiles, g.tiles_per_xcd, g.remap | ((e->reverse_odd && ((shift / RSX_RADIX_BITS) & 1)) ? 2 : 0), shift, flip_mask<Key>(e), mask,
@@ -490,6 +493,16 @@ int launch_reorder(rsx_engine* e, const void* in, void* out, const uint32_t* pin
 {
     if (count == 0) return RSX_OK;
     const bool payload = pin && pout;
+#if RSX_PRODUCT_SHAPE
+    if constexpr (sizeof(Key) == 8) {
+        // 64-bit keys WITH payload: the same 4096-key tiles (same table) ranked by 512 threads x 8 keys — 140 VGPRs and three waves per SIMD become ~90 and four;
+        // 1.149-1.184 -> 1.092-1.127 ms per launch (profiles/r03_ab_4bit_512x8.txt).  Every other 4-bit variant is 1-4 % slower that way and keeps 256 x 16.
+        if (payload && (e->reorder_wide >= 0 ? e->reorder_wide != 0 : true)) {
+            return next_shift >= 0 ? launch_reorder_t<Key, true, true, false, 8, 512>(e, in, out, pin, pout, count, shift, mask, next_shift, fold_paste)
+                                   : launch_reorder_t<Key, true, false, false, 8, 512>(e, in, out, pin, pout, count, shift, mask, 0, fold_paste);
+        }
+    }
+#endif
     if (next_shift >= 0) {
         return payload ? launch_reorder_t<Key, true, true>(e, in, out, pin, pout, count, shift, mask, next_shift, fold_paste)
                        : launch_reorder_t<Key, false, true>(e, in, out, nullptr, nullptr, count, shift, mask, next_shift, fold_paste);
@@ -498,11 +511,11 @@ int launch_reorder(rsx_engine* e, const void* in, void* out, const uint32_t* pin
                    : launch_reorder_t<Key, false, false>(e, in, out, nullptr, nullptr, count, shift, mask, 0, fold_paste);
 }
 
-template <typename Key, bool PAYLOAD, bool LOOKAHEAD, bool RANGED = false>
+template <typename Key, bool PAYLOAD, bool LOOKAHEAD, bool RANGED = false, int KPT = kKeysPerThread, int THREADS = kTileThreads>
 int allow_lds()
 {
-    using L = rsx::ReorderLayout<Key, kTileThreads, kKeysPerThread, (!RANGED && RSX_ALIAS_COUNTERS != 0)>;
-    RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder_kernel<Key, kTileThreads, kKeysPerThread, PAYLOAD, LOOKAHEAD, RANGED>),
+    using L = rsx::ReorderLayout<Key, THREADS, KPT, (!RANGED && RSX_ALIAS_COUNTERS != 0)>;
+    RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder_kernel<Key, THREADS, KPT, PAYLOAD, LOOKAHEAD, RANGED>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L::BYTES) + (64 << 10)),
             RSX_INITIALIZATION_FAILED);
     return RSX_OK;
@@ -1044,13 +1057,16 @@ int sort_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext_
         return rc;
     }
 #endif
+#if RSX_PRODUCT_SHAPE
     if (e->tile_sort && e->profile != 1 && count > 0 && count <= static_cast<uint64_t>(kTileKeys) && e->first_pass < e->last_pass) {
         return sort_tile_enqueue<Key>(e, ext_keys, ext_perm, count);
     }
+#endif
     if (e->self_scan && e->lookahead && !e->fold_paste && count > static_cast<uint64_t>(kTileKeys) && e->ntiles(count) <= e->self_scan_max && e->first_pass < e->last_pass) {
         if (count <= e->small_tile_max_keys) return sort_selfscan_enqueue<Key, kSmallKeysPerThread>(e, ext_keys, ext_perm, count);
         return sort_selfscan_enqueue<Key>(e, ext_keys, ext_perm, count);
     }
+#if RSX_PRODUCT_SHAPE
     {
         const uint32_t groups = static_cast<uint32_t>((e->ntiles(count) + rsx::kScanTiles - 1) / rsx::kScanTiles);
         // (profile mode 1 keeps the separate scan launches: timeScan / timePaste would otherwise be empty; a captured graph would replay a stale epoch)
@@ -1060,6 +1076,7 @@ int sort_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext_
             return sort_inline_enqueue<Key>(e, ext_keys, ext_perm, count);
         }
     }
+#endif
     // Ping-pong.  With external input the first pass reads the caller's buffer (never
     // written) and the chain continues inside the engine's two buffers.
     const void* in = ext_keys ? ext_keys : e->keys[e->cur];
@@ -1397,6 +1414,7 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
     if (const char* env = std::getenv("RSX_RADIX_BITS")) e->radix_bits = std::atoi(env) == 8 ? 8 : 4;
     if (const char* env = std::getenv("RSX_REORDER_EXTRA_LDS_KB")) e->reorder_extra_lds = std::atoi(env) < 0 ? -1L : static_cast<long>(std::min(64, std::atoi(env))) * 1024;
     if (const char* env = std::getenv("RSX_R8_PACKED")) e->r8_packed = std::atoi(env) != 0;
+    if (const char* env = std::getenv("RSX_REORDER_WIDE")) e->reorder_wide = std::max(-1, std::min(1, std::atoi(env)));
     if (const char* env = std::getenv("RSX_R8_WIDE")) e->r8_wide = std::max(-1, std::min(1, std::atoi(env)));
     if (const char* env = std::getenv("RSX_R8_STAY")) e->r8_stay = std::max(-1, std::min(8, std::atoi(env)));
     if (const char* env = std::getenv("RSX_R8_EXTRA_LDS_KB")) e->r8_extra_lds = std::atoi(env) < 0 ? -1L : static_cast<long>(std::min(96, std::atoi(env))) * 1024;
@@ -1508,6 +1526,7 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
         return bail(RSX_INITIALIZATION_FAILED, "hipMemsetAsync(globsum)", err);
 
     int rc = RSX_OK;
+#if RSX_PRODUCT_SHAPE
     {
         auto allow_tile = [](const void* fn, size_t bytes) { return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)); };
         using L32 = rsx::TileSortLayout<uint32_t, kTileThreads, kKeysPerThread>;
@@ -1518,6 +1537,11 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
             allow_tile(reinterpret_cast<const void*>(&rsx::tile_sort_kernel<uint64_t, kTileThreads, kKeysPerThread, true>), L64::BYTES) != hipSuccess)
             rc = fail(RSX_INITIALIZATION_FAILED, "hipFuncSetAttribute(tile_sort_kernel)");
     }
+#endif
+#if RSX_PRODUCT_SHAPE
+    if (rc == RSX_OK) rc = allow_lds<uint64_t, true, false, false, 8, 512>();
+    if (rc == RSX_OK) rc = allow_lds<uint64_t, true, true, false, 8, 512>();
+#endif
     if (rc == RSX_OK) rc = allow_lds<uint32_t, false, false>();
     if (rc == RSX_OK) rc = allow_lds<uint32_t, true, false>();
     if (rc == RSX_OK) rc = allow_lds<uint64_t, false, false>();

@@ -1243,3 +1243,29 @@ def test_8bit_scatter_on_512_thread_workgroups_is_exact(mod, oracle, dt, n):
                     e.sort()
                     ks = e.download()
                 assert np.array_equal(ks, want_k)
+
+
+@pytest.mark.parametrize("dt", ["uint64", "int64"])
+@pytest.mark.parametrize("n", [(1 << 23) + 4099, 5 * 4096 * 300 + 1])
+def test_4bit_reorder_of_64bit_keys_with_payload_on_either_workgroup_shape(mod, oracle, dt, n):
+    """RSX_REORDER_WIDE (read at rsx_create; -1 = policy: on): the 4-bit reorder of 64-bit keys with payload on 512 threads x 8 keys and on
+    256 x 16 — same tiles and tables — gives the same keys, the same stable payload order and the same final table."""
+    import os
+    keys = oracle.dataset("SeededUniform", dt, n, seed=n % 23)
+    keys[::6] = keys[1]
+    want_p = np.argsort(keys, kind="stable").astype(np.uint32)
+    tables = []
+    for wide in ("1", "0"):
+        os.environ["RSX_REORDER_WIDE"] = wide
+        try:
+            e = mod.Engine(dt, n, payload=True)
+        finally:
+            del os.environ["RSX_REORDER_WIDE"]
+        with e:
+            e.upload(keys, np.arange(n, dtype=np.uint32))
+            e.sort()
+            g = e.geometry()
+            ks, ps, hist = e.download(want_perm=True, hist_cap=int(g.table_len))
+        assert np.array_equal(ks, keys[want_p]) and np.array_equal(ps, want_p)
+        tables.append(hist)
+    assert np.array_equal(tables[0], tables[1])

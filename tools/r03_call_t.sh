@@ -1,6 +1,8 @@
 #!/bin/bash
+# 4-bit chain on 512-thread x 8-key workgroups (same 4096-key tiles; probe build) against the product's 256 x 16
 cd ${GRAFT_REPO_ROOT:-/root/repo}; O=gpurun_out/r03t; mkdir -p $O
-export MODE_ENGINES=6 MODE_PAYLOAD=1 MODE_BITS=8 MODE_SORTS=10
-for kb in 0 16; do echo "-- uint64+payload 8-bit, RSX_R8_EXTRA_LDS_KB=$kb" | tee -a $O/modes_u64pay8.txt; MODE_DTYPE=uint64 MODE_SORTS=6 RSX_R8_EXTRA_LDS_KB=$kb python tools/mode_probe.py 2>&1 | grep engine | tee -a $O/modes_u64pay8.txt; done
-for kb in 0 8; do echo "-- uint32+payload 8-bit (packed), RSX_R8_EXTRA_LDS_KB=$kb" | tee -a $O/modes_u32pay8.txt; RSX_R8_EXTRA_LDS_KB=$kb python tools/mode_probe.py 2>&1 | grep engine | tee -a $O/modes_u32pay8.txt; done
-echo "-- uint32+payload 8-bit, unpacked, 0" | tee -a $O/modes_u32pay8.txt; RSX_R8_PACKED=0 RSX_R8_EXTRA_LDS_KB=0 python tools/mode_probe.py 2>&1 | grep engine | tee -a $O/modes_u32pay8.txt
+V=tools/_variants/libradixsort_hip_t512k8.so
+for a in "--dtype uint64 --dataset RandomDistributed" "--payload"; do
+  RSX_LIB=$V python bench.py --no-cpu-baseline --steps 3 $a 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('probe build verified:', d['config']['verified'], d['ms_per_step'])"
+done
+ROUNDS=2 bash tools/ab_lib.sh $V -- "--dtype uint64 --dataset RandomDistributed" "--dtype uint64 --dataset RandomDistributed --payload" "" "--payload" "--dtype uint64 --dataset Zeros" 2>&1 | tee $O/ab_4bit_512x8.txt
