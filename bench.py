@@ -423,7 +423,7 @@ def main() -> None:
                        else f"msd-partition[{sorter.last_path}] x{world} + all_to_all (RCCL) + local LSD sort"),
                    "verified": verified},
         "roofline": {
-            "bound": "hbm", "kernel": "reorder_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "bound": "hbm", "kernel": "reorder_kernel" if args.radix_bits == 4 else "reorder8_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": load_traffic(workload),
             "algorithmic_bytes_per_launch": scatter_bytes, "avg_launch_ms": round(reorder_ms, 5),
             "launches_per_step": launches_per_step,
