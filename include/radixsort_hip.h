@@ -135,7 +135,7 @@ typedef struct rsx_runtimes {
 } rsx_runtimes;
 
 typedef struct rsx_geometry {
-    uint32_t tile_threads;     /* workgroup size of histogram/reorder */
+    uint32_t tile_threads;     /* workgroup size of histogram/reorder (two scatter variants over 64-bit keys rank the same tile with 2x the threads and half the keys per thread) */
     uint32_t keys_per_thread;
     uint32_t tile_keys;        /* keys per tile = table column */
     uint32_t scan_block;       /* tiles per scan group: a group = this many consecutive tiles of ONE digit */
