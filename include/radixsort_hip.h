@@ -80,23 +80,6 @@ typedef enum rsx_option {
                                  stream of the same device; engines that scan at the same time share that budget — a caller running k > 2
                                  of them concurrently on one device sets resident / k here.  Values are clamped to what is resident; -1 =
                                  default; 0 = never.  Larger tables take scan #1, then scan #2 + paste (two launches), same table. */
-    RSX_OPT_INLINE_SCAN = 17, /* (default 0: measured 5-20 % slower than the scan launch it removes, kept as a tested option) 1: inside rsx_sort, tables beyond the self-scan and of at most RSX_OPT_INLINE_SCAN_MAX_GROUPS scan groups get no
-                                 scan launch of their own: the first workgroups of every reorder launch scan the pass's table (the fused scan's
-                                 workgroup body, entries published write-through with a per-group ready word) before they turn to their tiles,
-                                 and every workgroup waits for the word of its tile's group while it ranks its keys.  passes + 1 dependent
-                                 launches instead of 2 passes + 1.  Same table, same result; not taken while RSX_OPT_PROFILE is 1, with
-                                 RSX_OPT_GRAPH, or beyond RSX_OPT_FUSED_SCAN_MAX_GROUPS (the same co-residency rule). */
-    RSX_OPT_INLINE_SCAN_MAX_GROUPS = 18, /* (default 64 = 2^26 keys) largest table, in scan groups, that takes the inline scan */
-    RSX_OPT_REORDER8_KERNEL = 19, /* which scatter kernel the 8-bit passes use — same result, measured alternatives kept selectable (profiles/r03_tuning_log.md §1):
-                                 1 (default) two ranking rounds of the 4-bit machinery, the tile staged twice; 2 the same ranking with keys and
-                                 payload making ONE trip through LDS (better on Range, worse elsewhere); 3 ranks from one returning LDS atomic per
-                                 key on per-wave counters (fewest instructions, but LDS atomics under bank conflicts make it 1.6x slower on random
-                                 keys; faster on constant data); 3 relies on LDS atomics serving lanes in ascending lane order, probed on the
-                                 device at first use — where the probe fails kernel 1 runs instead. */
-    RSX_OPT_REORDER8_STAY = 20, /* kernel 1 of the 8-bit passes as a grid that stays: N > 0 launches N workgroups per CU that walk the tiles (each XCD its
-                                 own range, neighbours in flight together) and load their next tile while they rank the current one; 0 = one
-                                 workgroup per tile; -1 (default) = the engine's per-variant policy.  At most 8. */
-    RSX_OPT_DEBUG_RAISE_SCAN_TIMEOUT = 16, /* tests only: enqueue the store a timed-out fused scan makes (see rsx_check_status) */
     RSX_OPT_RADIX_BITS = 10,  /* digit width of the rsx_sort chain: 4 (default, the reference's _NUM_BITS_PER_RADIX, src/Parameters.h:25) or 8.
                                  With 8 a pass sorts by a whole byte (two stable 4-bit rounds inside LDS, one scatter of up to
                                  256 runs per tile): half the passes over HBM.  Same result.  Pass ranges (RSX_OPT_FIRST_PASS /
@@ -316,6 +299,39 @@ int rsx_peer_free(rsx_engine* e, void* d_ptr);
 int rsx_peer_open(rsx_engine* e, const void* ipc_handle, void** d_ptr);
 int rsx_peer_close(rsx_engine* e, void* d_ptr);
 int rsx_peer_enable(rsx_engine* e, int peer_device);
+/* ---- exchange step of the sharded sort on the top B <= 8 key bits (nothing in the reference: one device, one in-order
+ * queue, Common/ComputeState.cpp:88-101).  world = 1, 2, 4, 8 or 16 ranks own k = 2^bits / world consecutive buckets of the top `bits`
+ * bits each; bucket rank * k + w belongs to WAVE w, and every rank receives its k waves one after the other, so that wave w can be sorted —
+ * all its keys at a rank share the top `bits` bits: passes [0, ceil((keybits - bits) / 4)) suffice — while wave w + 1 is still on the links.
+ * More bits = more, smaller waves = a smaller exposed first wave.  All calls are asynchronous on the engine's stream unless stated.
+ *   rsx_msd_count    one read of the shard: d_counts (DEVICE memory, 256 x uint64) receives the keys per bucket in natural bucket order
+ *                    (entries past 2^bits are 0) — the row the caller all_gathers; no host synchronisation.
+ *   rsx_msd_scatter  must follow on the same keys: groups the shard (stable) into d_staging in wave-major order [wave][destination rank]
+ *                    (inside a segment: by the remaining bits of the key's top byte).  Needs only THIS rank's counts, i.e. it may run while
+ *                    the all_gather is still in flight.
+ *   rsx_msd_plan     from the gathered table d_table[source rank * stride + bucket] (+ every rank's receive and output capacity in keys at
+ *                    [.. + cap_at] and [.. + cap_at + 1]) computes ON THE DEVICE, on hip_stream (NULL = the engine's): where each of this
+ *                    rank's (wave, destination) segments lands in the destination's receive buffer (waves 16-byte aligned, sources in rank
+ *                    order), what this rank receives per wave, every rank's load, and the capacity verdict — then copies the host's part to
+ *                    pinned memory.  rsx_msd_plan_wait blocks the HOST until that copy has landed (the device never waits for the host) and
+ *                    returns it: wave_start / wave_count (2^bits / world entries, in keys, THIS rank's receive buffer), loads (world entries),
+ *                    verdict (0 = fits; bit r set = rank r's buffers are too small — then no push writes anything, on any rank).
+ *   rsx_msd_push     wave `wave`: copies this rank's segments of that wave from staging straight into the destinations' receive buffers:
+ *                    d_peer_keys / d_peer_payload = DEVICE arrays of `world` base addresses as THIS rank addresses them (rsx_peer_alloc /
+ *                    rsx_peer_open / rsx_peer_enable).  `parts` workgroups per destination (<= 0: 16): a link-bound copy that leaves the CUs to
+ *                    the local sorts.  The caller fences the wave across ranks (one tiny all_reduce, or its own flags) before sorting it.
+ * Plumbing for hosts that do not link HIP themselves: rsx_copy_to_device / _from_device / _on_device (asynchronous on the engine's
+ * stream; pageable host memory serialises, pin it with rsx_pin_host) and rsx_wait_for (e's stream waits for everything enqueued on
+ * other's stream so far — engines of one process, any devices). */
+int rsx_msd_count(rsx_engine* e, const void* d_keys, uint64_t n, int bits, int world, uint64_t* d_counts);
+int rsx_msd_scatter(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n, void* d_staging, uint32_t* d_staging_payload);
+int rsx_msd_plan(rsx_engine* e, const uint64_t* d_table, uint32_t stride, uint32_t cap_at, int rank, void* hip_stream);
+int rsx_msd_plan_wait(rsx_engine* e, uint64_t* wave_start, uint64_t* wave_count, uint64_t* loads, uint64_t* verdict);
+int rsx_msd_push(rsx_engine* e, int wave, const void* d_staging, const uint32_t* d_staging_payload, const uint64_t* d_peer_keys, const uint64_t* d_peer_payload, int parts);
+int rsx_copy_to_device(rsx_engine* e, void* d_dst, const void* host_src, uint64_t bytes);
+int rsx_copy_from_device(rsx_engine* e, void* host_dst, const void* d_src, uint64_t bytes);
+int rsx_copy_on_device(rsx_engine* e, void* d_dst, const void* d_src, uint64_t bytes);
+int rsx_wait_for(rsx_engine* e, rsx_engine* other);
 int rsx_key_range(rsx_engine* e, const void* d_keys, uint64_t n, uint64_t* lo, uint64_t* hi);
 int rsx_partition_range(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n, uint64_t lo, int shift, uint64_t mul,
                         void* d_keys_out, uint32_t* d_payload_out, uint64_t* bucket_offsets);

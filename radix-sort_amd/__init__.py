@@ -30,7 +30,12 @@ STATUS_NAMES = [
     "PROGRAM_CREATION_FAILED", "NO_SOURCE_FOUND", "LOADING_SOURCE_FAILED",
 ]
 
-OPT_PROFILE, OPT_XCD_REMAP, OPT_FIRST_PASS, OPT_LAST_PASS, OPT_LOOKAHEAD, OPT_REF_DIAGNOSTICS, OPT_GRAPH, OPT_SMALL_SCAN, OPT_TILE_SORT, OPT_FUSED_SCAN, OPT_RADIX_BITS, OPT_SELF_SCAN, OPT_SMALL_TILE_MAX_KEYS, OPT_XCD_PHASE, OPT_SELF_SCAN_MAX_TILES, OPT_FUSED_SCAN_MAX_GROUPS, OPT_DEBUG_RAISE_SCAN_TIMEOUT, OPT_INLINE_SCAN, OPT_INLINE_SCAN_MAX_GROUPS, OPT_REORDER8_KERNEL, OPT_REORDER8_STAY = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20
+# rsx_option (include/radixsort_hip.h)
+OPT_PROFILE, OPT_XCD_REMAP, OPT_FIRST_PASS, OPT_LAST_PASS, OPT_LOOKAHEAD, OPT_REF_DIAGNOSTICS, OPT_GRAPH, OPT_SMALL_SCAN, OPT_TILE_SORT, OPT_FUSED_SCAN = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
+OPT_RADIX_BITS, OPT_SELF_SCAN, OPT_SMALL_TILE_MAX_KEYS, OPT_XCD_PHASE, OPT_SELF_SCAN_MAX_TILES, OPT_FUSED_SCAN_MAX_GROUPS = 10, 11, 12, 13, 14, 15
+# rsx_experimental_option (include/radixsort_hip_experiments.h): known to the EXPERIMENTS build only (experiments()); the product library refuses them
+XOPT_DEBUG_RAISE_SCAN_TIMEOUT, XOPT_INLINE_SCAN, XOPT_INLINE_SCAN_MAX_GROUPS, XOPT_REORDER8_KERNEL, XOPT_REORDER8_STAY = 16, 17, 18, 19, 20
+EXPERIMENTS_LIB_PATH = os.path.join(os.path.dirname(_HERE), "tools", "_variants", "libradixsort_hip_experiments.so")
 
 # every symbol include/radixsort_hip.h declares (tests/test_capi_symbols.py checks the header against this)
 SYMBOLS = [
@@ -38,7 +43,7 @@ SYMBOLS = [
     "rsx_create", "rsx_destroy", "rsx_set_stream", "rsx_get_stream", "rsx_set_option", "rsx_get_geometry", "rsx_resize",
     "rsx_upload", "rsx_fill_pad", "rsx_download", "rsx_pin_host", "rsx_unpin_host", "rsx_pipeline_submit", "rsx_pipeline_wait", "rsx_host_device_pointer",
     "rsx_histogram", "rsx_scan", "rsx_paste", "rsx_reorder", "rsx_sort", "rsx_sync", "rsx_check_status",
-    "rsx_sort_from", "rsx_partition", "rsx_partition_count", "rsx_partition_scatter", "rsx_sample_keys", "rsx_partition_count_split", "rsx_partition_scatter_split", "rsx_partition_count_waves", "rsx_partition_count_waves_device", "rsx_partition_scatter_waves", "rsx_partition_scatter_waves_peer", "rsx_peer_alloc", "rsx_peer_free", "rsx_peer_open", "rsx_peer_close", "rsx_peer_enable", "rsx_sort_from_to", "rsx_key_range", "rsx_partition_range", "rsx_result_device", "rsx_copy_result", "rsx_tile_map", "rsx_timings",
+    "rsx_sort_from", "rsx_partition", "rsx_partition_count", "rsx_partition_scatter", "rsx_sample_keys", "rsx_partition_count_split", "rsx_partition_scatter_split", "rsx_partition_count_waves", "rsx_partition_count_waves_device", "rsx_partition_scatter_waves", "rsx_partition_scatter_waves_peer", "rsx_peer_alloc", "rsx_peer_free", "rsx_peer_open", "rsx_peer_close", "rsx_peer_enable", "rsx_sort_from_to", "rsx_msd_count", "rsx_msd_scatter", "rsx_msd_plan", "rsx_msd_plan_wait", "rsx_msd_push", "rsx_copy_to_device", "rsx_copy_from_device", "rsx_copy_on_device", "rsx_wait_for", "rsx_key_range", "rsx_partition_range", "rsx_result_device", "rsx_copy_result", "rsx_tile_map", "rsx_timings",
 ]
 
 
@@ -147,6 +152,15 @@ def load_library() -> C.CDLL:
         "rsx_peer_close": ([P, P], I),
         "rsx_peer_enable": ([P, I], I),
         "rsx_sort_from_to": ([P, P, P, U64, I, I, P, P], I),
+        "rsx_msd_count": ([P, P, U64, I, I, P], I),
+        "rsx_msd_scatter": ([P, P, P, U64, P, P], I),
+        "rsx_msd_plan": ([P, P, C.c_uint32, C.c_uint32, I, P], I),
+        "rsx_msd_plan_wait": ([P, C.POINTER(U64), C.POINTER(U64), C.POINTER(U64), C.POINTER(U64)], I),
+        "rsx_msd_push": ([P, I, P, P, P, P, I], I),
+        "rsx_copy_to_device": ([P, P, P, U64], I),
+        "rsx_copy_from_device": ([P, P, P, U64], I),
+        "rsx_copy_on_device": ([P, P, P, U64], I),
+        "rsx_wait_for": ([P, P], I),
         "rsx_key_range": ([P, P, U64, C.POINTER(U64), C.POINTER(U64)], I),
         "rsx_partition_range": ([P, P, P, U64, U64, I, U64, P, P, C.POINTER(U64)], I),
         "rsx_result_device": ([P, C.POINTER(P), C.POINTER(P)], I),
@@ -160,6 +174,27 @@ def load_library() -> C.CDLL:
         fn.restype = res
     _lib = lib
     return lib
+
+
+def variant(lib_path: str):
+    """A second, independent instance of this binding over ANOTHER build of the library (A/B builds, the experiments build):
+    its own module object, its own dlopen; engines of the two never mix."""
+    if not os.path.exists(lib_path):
+        raise FileNotFoundError(f"{lib_path} is missing (tools/build_variant.sh, or __graft_entry__.build())")
+    name = __name__ + "_variant_" + os.path.splitext(os.path.basename(lib_path))[0]
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, os.path.join(_HERE, "__init__.py"), submodule_search_locations=[_HERE])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    mod.LIB_PATH = lib_path
+    return mod
+
+
+def experiments():
+    """The binding over the experiments build (-DRSX_EXPERIMENTS: rejected kernel variants, inline table scan, test hooks)."""
+    return variant(EXPERIMENTS_LIB_PATH)
 
 
 def device_count() -> int:
@@ -397,6 +432,32 @@ class Engine:
         self._check(self.lib.rsx_sort_from_to(
             self._h, C.c_void_p(d_keys), C.c_void_p(d_payload) if d_payload else None, n, first_pass, last_pass,
             C.c_void_p(d_keys_out), C.c_void_p(d_payload_out) if d_payload_out else None), "rsx_sort_from_to")
+
+    # -- exchange step of the sharded sort on the top B <= 8 bits ----------------
+    def msd_count(self, d_keys: int, n: int, bits: int, world: int, d_counts: int) -> None:
+        """Keys per bucket of the top `bits` bits into device memory (256 x uint64 at d_counts, natural order), asynchronously."""
+        self._check(self.lib.rsx_msd_count(self._h, C.c_void_p(d_keys), n, bits, world, C.c_void_p(d_counts)), "rsx_msd_count")
+
+    def msd_scatter(self, d_keys: int, n: int, d_staging: int, d_payload: int | None = None, d_staging_payload: int | None = None) -> None:
+        self._check(self.lib.rsx_msd_scatter(self._h, C.c_void_p(d_keys), C.c_void_p(d_payload) if d_payload else None, n, C.c_void_p(d_staging),
+                                             C.c_void_p(d_staging_payload) if d_staging_payload else None), "rsx_msd_scatter")
+
+    def msd_plan(self, d_table: int, stride: int, cap_at: int, rank: int, hip_stream: int = 0) -> None:
+        self._check(self.lib.rsx_msd_plan(self._h, C.c_void_p(d_table), stride, cap_at, rank, C.c_void_p(hip_stream) if hip_stream else None), "rsx_msd_plan")
+
+    def msd_plan_wait(self, waves: int, world: int) -> tuple[list[int], list[int], list[int], int]:
+        """(first slot of every wave in this rank's receive buffer, keys of every wave, keys every rank ends up with, verdict bits)"""
+        ws, wc, ld, v = (C.c_uint64 * waves)(), (C.c_uint64 * waves)(), (C.c_uint64 * world)(), C.c_uint64()
+        self._check(self.lib.rsx_msd_plan_wait(self._h, ws, wc, ld, C.byref(v)), "rsx_msd_plan_wait")
+        return [int(x) for x in ws], [int(x) for x in wc], [int(x) for x in ld], int(v.value)
+
+    def msd_push(self, wave: int, d_staging: int, d_peer_keys: int, d_staging_payload: int | None = None, d_peer_payload: int | None = None, parts: int = 0) -> None:
+        self._check(self.lib.rsx_msd_push(self._h, wave, C.c_void_p(d_staging), C.c_void_p(d_staging_payload) if d_staging_payload else None,
+                                          C.c_void_p(d_peer_keys), C.c_void_p(d_peer_payload) if d_peer_payload else None, parts), "rsx_msd_push")
+
+    def wait_for(self, other: "Engine") -> None:
+        """This engine's stream waits for everything enqueued on `other`'s stream so far."""
+        self._check(self.lib.rsx_wait_for(self._h, other._h), "rsx_wait_for")
 
     def key_range(self, d_keys: int, n: int) -> tuple[int, int]:
         lo, hi = C.c_uint64(), C.c_uint64()

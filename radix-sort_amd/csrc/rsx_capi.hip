@@ -8,6 +8,9 @@
 // `finish()`: everything is enqueued on one HIP stream and the host synchronises
 // only in upload/download/timings, as the C ABI header states.
 #include "radixsort_hip.h"
+#ifdef RSX_EXPERIMENTS
+#include "radixsort_hip_experiments.h"
+#endif
 #include "rsx_kernels.hpp"
 
 #include <hip/hip_runtime.h>
@@ -132,10 +135,13 @@ struct rsx_engine {
     uint32_t scan_epoch = 0;                    // launch count of the fused scan (tags the granules; never 0)
     uint32_t* temp = nullptr;                   // grand total of scan #2
     uint32_t* counts_next = nullptr;            // look-ahead histogram of the next pass, [tile][digit]
+#ifdef RSX_EXPERIMENTS
     uint32_t* counts_next2 = nullptr;           // inline-scan chain: the second of two alternating count buffers (the scan of a launch reads one, its look-ahead adds into the other)
     uint32_t* scan_ready = nullptr;             // inline-scan chain: [group] = epoch of the launch whose table entries of that group are published
-    int inline_scan = 0;                        // rsx_sort: mid-size sorts run the table scan inside the reorder launch (RSX_OPT_INLINE_SCAN, env RSX_INLINE_SCAN); measured SLOWER than the scan launch (profiles/r03_tuning_log.md §4): off
-    uint32_t inline_scan_max_groups = 64;       // ... for tables of at most this many scan groups (2^26 keys; env RSX_INLINE_SCAN_MAX_GROUPS), never beyond fused_scan_limit
+    int inline_scan = 0;                        // rsx_sort: mid-size sorts run the table scan inside the reorder launch (RSX_XOPT_INLINE_SCAN); measured SLOWER than the scan launch (profiles/r03_tuning_log.md §4)
+    uint32_t inline_scan_max_groups = 64;       // ... for tables of at most this many scan groups (2^26 keys), never beyond the inline kernels' own co-residency limit
+    uint32_t inline_scan_limit = 0;             // workgroups of the INLINE reorder kernels resident at once / 2 (occupancy query, rsx_create)
+#endif
 #ifdef RSX_STAMPS
     unsigned long long* stamps = nullptr;       // diagnostic build: 16 phase stamps per tile of ONE chosen launch
     int stamp_pass = -1;                        // env RSX_STAMP_PASS: the pass whose reorder launch writes them
@@ -159,18 +165,30 @@ struct rsx_engine {
     uint32_t* starts_dev = nullptr;             // 16 bucket starts (rsx_partition)
     uint32_t* starts_host = nullptr;            // pinned mirror
     uint64_t table_cap = 0;
+#ifdef RSX_EXPERIMENTS
     // Large buffers may be backed by separately created physical chunks mapped into one virtual range in a shuffled order
-    // (RSX_ALLOC_MODE, big_alloc below): which physical pages a buffer gets decides how the scatter's 16..512 write fronts —
-    // a power of two apart for 2^k uniform keys — fall onto L2 sets / HBM banks (profiles/r03_tuning_log.md §5).
+    // (env RSX_ALLOC_MODE, big_alloc): which physical pages a buffer gets decides how the scatter's 16..512 write
+    // fronts — a power of two apart for 2^k uniform keys — fall onto L2 sets / HBM banks (profiles/r03_tuning_log.md §5).
     struct BigBuf {
         void* base = nullptr;
         size_t size = 0;
         std::vector<hipMemGenericAllocationHandle_t> chunks;     // empty: plain hipMalloc
     };
     std::vector<BigBuf> big;
-    int alloc_mode = 0;         // 0 hipMalloc; 1 chunks mapped in creation order; 2 chunks mapped in a shuffled order (env RSX_ALLOC_MODE)
-    size_t alloc_chunk = 0;     // chunk bytes (env RSX_ALLOC_CHUNK_MB; 0 = the recommended granularity)
+    int alloc_mode = 0;         // 0 hipMalloc; 1 chunks mapped in creation order; 2 chunks mapped in a shuffled order
+    size_t alloc_chunk = 0;     // chunk bytes (env RSX_ALLOC_CHUNK_MB; 0 = 32 MiB)
+#endif
     unsigned long long* peer_dev = nullptr;     // peer-store exchange: 16 key + 16 payload destination addresses (allocated on first use)
+    // exchange step of the sharded sort on the top B <= 8 bits (capi_msd.inc; all allocated on first use)
+    rsx::MsdPlan* msd_plan = nullptr;           // device: segments of this rank per (wave, destination), what it receives per wave, loads, verdict
+    rsx::MsdPlan* msd_plan_host = nullptr;      // pinned mirror of the part the host needs
+    uint32_t* msd_starts = nullptr;             // device: first staging slot of each of the 256 fine buckets, wave-major order
+    hipEvent_t msd_event = nullptr;             // the plan (and its copy to the host) is complete
+    hipEvent_t order_event = nullptr;           // rsx_wait_for: "everything enqueued on this engine's stream so far"
+    const void* msd_keys = nullptr;             // rsx_msd_count left table8 / cbase8 for exactly this input ...
+    uint64_t msd_n = 0;
+    int msd_bits = 0, msd_world = 0;            // ... partitioned on this many top bits for this many ranks
+    bool msd_planned = false;
 
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -192,12 +210,16 @@ struct rsx_engine {
     int xcd_remap = 1;
     uint64_t options_epoch = 0;
     int64_t xcd_phase = -1;     // RSX_OPT_XCD_PHASE / env RSX_XCD_PHASE, in tiles: -1 = a range's eighth (the XCDs spread evenly over the walk), 0 = lockstep
-    int reverse_odd = 0;                        // odd passes walk the tiles backwards (env RSX_REVERSE_ODD; measured, see the tuning log)
     int lookahead = 1;          // rsx_sort builds pass p+1's histogram inside pass p's reorder
     int small_scan = 1;         // rsx_sort: one-workgroup scan+paste for tables of <= 1024 tiles (env RSX_SMALL_SCAN)
     uint64_t radix8_min_keys = 1u << 19;        // 8-bit passes only above this many keys (env RSX_RADIX8_MIN_KEYS; at least one tile)
     int radix_bits = 4;         // RSX_OPT_RADIX_BITS: 4 (the reference's configuration) or 8 (half the passes; rsx_sort chain only)
-    int reorder8_version = 1;   // env RSX_REORDER8_V / RSX_OPT_REORDER8_KERNEL: 3 = ranks from one returning LDS atomic per key (needs lds_atomics_ordered), 1 = two ranking rounds of the 4-bit machinery, 2 = its one-trip variant
+#ifdef RSX_EXPERIMENTS
+    int reorder8_version = 1;   // RSX_XOPT_REORDER8_KERNEL: 3 = ranks from one returning LDS atomic per key (needs lds_atomics_ordered), 1 = two ranking rounds of the 4-bit machinery (the product's), 2 = its one-trip variant
+    int r8_stay = -1;           // kernel 1 as a grid that stays (rsx::reorder8_stay_kernel): workgroups per CU of that grid, 0 / -1 = one workgroup per tile (RSX_XOPT_REORDER8_STAY)
+    int lds_atomics_ordered = -1;               // -1 not probed yet; 1: ds_add_rtn serves lanes in ascending lane order on this device (lds_atomic_order_probe_kernel); 0: it does not, kernel 3 is refused
+    uint32_t* tickets8 = nullptr;               // staying 8-bit scatter: [pass of the chain][XCD] tile tickets, zeroed at the start of every sort that uses them
+#endif
     // Unused dynamic LDS per workgroup of the default 8-bit scatter = fewer workgroups per CU.  The 8-bit scatter leaves a tile as ~256 runs of ~16 keys whose first and last
     // sectors are completed by the NEIGHBOURING tile's runs; the halves merge only while the line is still in the XCD's L2, and the lines held open grow with the tiles in
     // flight: 64-bit elements (uint64 keys, or uint32 key + payload packed) overflow the 4 MiB at 3 workgroups per CU and are 10-27 % faster at 2
@@ -208,15 +230,11 @@ struct rsx_engine {
     // (profiles/r03_4bit_workgroups_per_cu.txt, r03_modes_u32pay4_workgroups_per_cu.txt)
     long reorder_extra_lds = -1;
     int reorder_wide = -1;      // 4-bit reorder of 64-bit keys WITH payload on 512 threads x 8 keys (env RSX_REORDER_WIDE: 0 / 1, -1 = policy: on)
-    // default 8-bit scatter as a grid that stays (rsx::reorder8_stay_kernel): workgroups per CU of that grid, 0 = one workgroup per tile (env RSX_R8_STAY; -1 = policy)
-    int r8_stay = -1;
     // kernel 1 on workgroups of 512 threads x 8 keys (the same 4096-key tiles, tables and LDS bytes in flight; twice the waves): env RSX_R8_WIDE, -1 = policy
     int r8_wide = -1;
     int num_cus = 0;
     int r8_packed = 1;          // 8-bit scatter of uint32 keys WITH payload: key and payload as one 64-bit element through the ranking rounds (env RSX_R8_PACKED; kernel 1 only)
-    int lds_atomics_ordered = -1;               // -1 not probed yet; 1: ds_add_rtn serves lanes in ascending lane order on this device (lds_atomic_order_probe_kernel); 0: it does not, kernel 3 is refused
     bool radix8_ready = false;                  // the five tables below exist and the reorder8 kernels may use their LDS
-    uint32_t* tickets8 = nullptr;               // staying 8-bit scatter: [pass of the chain][XCD] tile tickets, zeroed at the start of every sort that uses them
     uint32_t* counts8 = nullptr;                // 8-bit digits: raw counts [tile][256] (allocated on first use)
     uint32_t* table8 = nullptr;                 //   group-local exclusive prefixes [tile][256]
     uint32_t* gsum8 = nullptr;                  //   per scan group: totals, then prefixes inside the group's chunk [group][256]
@@ -227,8 +245,6 @@ struct rsx_engine {
     uint32_t* cnt3[3] = {nullptr, nullptr, nullptr};      // self-scan: three rotating [tile][16] count buffers
     uint64_t small_tile_max_keys = 1u << 19;              // self-scan sorts of at most this many keys use tiles of 256 x 4 keys (env RSX_SMALL_TILE_MAX_KEYS; measured: -20 % up to 2^16, -16 % at 2^18, -6 % at 2^19, +20 % at 2^20)
     int tile_sort = 1;          // rsx_sort: inputs of at most one tile are sorted by ONE workgroup in ONE launch, all passes in LDS (env RSX_TILE_SORT)
-    int fold_paste = 0;         // reorder adds globsum itself (no paste launch): measured 3 % slower, off; env RSX_FOLD_PASTE
-    int scan_zeroes = 1;
     int first_pass = 0;
     int last_pass = 0;
 
@@ -354,11 +370,8 @@ int launch_scan(rsx_engine* e, uint64_t count, bool from_counts = false, bool sc
     e->globsum_valid = true;
     {
         Bracket b(e, PH_SCAN);
-        if (from_counts && e->scan_zeroes) {
+        if (from_counts) {
             hipLaunchKernelGGL((rsx::scan_blocks_kernel<true, true>), dim3(ngroups), dim3(rsx::kScanTiles), 0, e->stream, e->table, e->globsum,
-                               ntiles, ngroups, e->counts_next);
-        } else if (from_counts) {
-            hipLaunchKernelGGL((rsx::scan_blocks_kernel<true, false>), dim3(ngroups), dim3(rsx::kScanTiles), 0, e->stream, e->table, e->globsum,
                                ntiles, ngroups, e->counts_next);
         } else {
             hipLaunchKernelGGL((rsx::scan_blocks_kernel<false, false>), dim3(ngroups), dim3(rsx::kScanTiles), 0, e->stream, e->table, e->globsum,
@@ -408,11 +421,8 @@ bool launch_scan_fused(rsx_engine* e, uint64_t count, bool from_counts, int* rc)
     if (++e->scan_epoch == 0) e->scan_epoch = 1;
     {
         Bracket b(e, PH_SCAN);
-        if (from_counts && e->scan_zeroes) {
+        if (from_counts) {
             hipLaunchKernelGGL((rsx::scan_fused_kernel<true, true>), dim3(ngroups), dim3(rsx::kScanTiles), 0, e->stream, e->table, e->gsums, e->globsum2, e->temp,
-                               ntiles, ngroups, e->counts_next, e->scan_epoch, e->scan_timeout);
-        } else if (from_counts) {
-            hipLaunchKernelGGL((rsx::scan_fused_kernel<true, false>), dim3(ngroups), dim3(rsx::kScanTiles), 0, e->stream, e->table, e->gsums, e->globsum2, e->temp,
                                ntiles, ngroups, e->counts_next, e->scan_epoch, e->scan_timeout);
         } else {
             hipLaunchKernelGGL((rsx::scan_fused_kernel<false, false>), dim3(ngroups), dim3(rsx::kScanTiles), 0, e->stream, e->table, e->gsums, e->globsum2, e->temp,
@@ -434,10 +444,8 @@ bool launch_scan_small(rsx_engine* e, uint64_t count, bool from_counts, int* rc)
     e->globsum_valid = false;           // one workgroup scans the whole table: there are no group sums
     {
         Bracket b(e, PH_SCAN);
-        if (from_counts && e->scan_zeroes) {
+        if (from_counts) {
             hipLaunchKernelGGL((rsx::scan_small_kernel<true, true>), dim3(1), dim3(rsx::kSmallScanThreads), 0, e->stream, e->table, e->counts_next, e->temp, ntiles);
-        } else if (from_counts) {
-            hipLaunchKernelGGL((rsx::scan_small_kernel<true, false>), dim3(1), dim3(rsx::kSmallScanThreads), 0, e->stream, e->table, e->counts_next, e->temp, ntiles);
         } else {
             hipLaunchKernelGGL((rsx::scan_small_kernel<false, false>), dim3(1), dim3(rsx::kSmallScanThreads), 0, e->stream, e->table, e->counts_next, e->temp, ntiles);
         }
@@ -459,15 +467,14 @@ int launch_paste(rsx_engine* e, uint64_t count)
 
 // next_shift < 0: plain reorder.  next_shift >= 0: also count digit (key >> next_shift) & 15 per
 // OUTPUT tile into e->counts_next (all zero on entry: zeroed at the start of the sort and handed
-// back zeroed by the scan that consumes it).  fold_paste: the table holds block-local prefixes
-// and the kernel adds the scanned block sums itself (no paste launch).
+// back zeroed by the scan that consumes it).
 template <typename Key, bool PAYLOAD, bool LOOKAHEAD, bool RANGED = false, int KPT = kKeysPerThread, int THREADS = kTileThreads>
 int launch_reorder_t(rsx_engine* e, const void* in, void* out, const uint32_t* pin, uint32_t* pout, uint64_t count, int shift,
-                     uint32_t mask, int next_shift, bool fold_paste, Key lo = Key{0}, Key mul = Key{0}, uint32_t nsplit = 0,
+                     uint32_t mask, int next_shift, Key lo = Key{0}, Key mul = Key{0}, uint32_t nsplit = 0,
                      rsx::SelfScanArgs self = rsx::SelfScanArgs{nullptr, nullptr, nullptr}, uint32_t* next_counts = nullptr,
                      rsx::PeerArgs peer = rsx::PeerArgs{nullptr, nullptr})
 {
-    using L = rsx::ReorderLayout<Key, THREADS, KPT, (!RANGED && RSX_ALIAS_COUNTERS != 0)>;
+    using L = rsx::ReorderLayout<Key, THREADS, KPT>;
     const Grid g = grid_for(e, count, THREADS * KPT);
     e->last_in = in;
     e->last_shift = shift;
@@ -475,12 +482,12 @@ int launch_reorder_t(rsx_engine* e, const void* in, void* out, const uint32_t* p
     hipLaunchKernelGGL((rsx::reorder_kernel<Key, THREADS, KPT, PAYLOAD, LOOKAHEAD, RANGED>), dim3(g.blocks), dim3(THREADS),
                        L::BYTES + (KPT != kKeysPerThread ? 0u : e->reorder_extra_lds >= 0 ? static_cast<size_t>(e->reorder_extra_lds) : (PAYLOAD && sizeof(Key) == 4 && !RANGED) ? (16u << 10) : 0u),
                        e->stream, static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->table, count,
-                       g.ntiles, g.tiles_per_xcd, g.remap | ((e->reverse_odd && ((shift / RSX_RADIX_BITS) & 1)) ? 2 : 0), shift, flip_mask<Key>(e), mask,
+                       g.ntiles, g.tiles_per_xcd, g.remap, shift, flip_mask<Key>(e), mask,
                        next_counts ? next_counts : e->counts_next, next_shift,
 #ifdef RSX_STAMPS
                        (shift == e->stamp_pass * RSX_RADIX_BITS) ? reinterpret_cast<const uint32_t*>(e->stamps) : static_cast<const uint32_t*>(nullptr),
 #else
-                       fold_paste ? static_cast<const uint32_t*>(e->globsum) : static_cast<const uint32_t*>(nullptr),
+                       static_cast<const uint32_t*>(nullptr),      // (folding the paste into the scatter — it adds globsum[group] itself — was measured 3 % slower and removed in round 4)
 #endif
                        lo, mul, split_set<Key>(e, nsplit), self, peer);
     RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
@@ -489,7 +496,7 @@ int launch_reorder_t(rsx_engine* e, const void* in, void* out, const uint32_t* p
 
 template <typename Key>
 int launch_reorder(rsx_engine* e, const void* in, void* out, const uint32_t* pin, uint32_t* pout, uint64_t count, int shift,
-                   uint32_t mask, int next_shift = -1, bool fold_paste = false)
+                   uint32_t mask, int next_shift = -1)
 {
     if (count == 0) return RSX_OK;
     const bool payload = pin && pout;
@@ -498,27 +505,50 @@ int launch_reorder(rsx_engine* e, const void* in, void* out, const uint32_t* pin
         // 64-bit keys WITH payload: the same 4096-key tiles (same table) ranked by 512 threads x 8 keys — 140 VGPRs and three waves per SIMD become ~90 and four;
         // 1.149-1.184 -> 1.092-1.127 ms per launch (profiles/r03_ab_4bit_512x8.txt).  Every other 4-bit variant is 1-4 % slower that way and keeps 256 x 16.
         if (payload && (e->reorder_wide >= 0 ? e->reorder_wide != 0 : true)) {
-            return next_shift >= 0 ? launch_reorder_t<Key, true, true, false, 8, 512>(e, in, out, pin, pout, count, shift, mask, next_shift, fold_paste)
-                                   : launch_reorder_t<Key, true, false, false, 8, 512>(e, in, out, pin, pout, count, shift, mask, 0, fold_paste);
+            return next_shift >= 0 ? launch_reorder_t<Key, true, true, false, 8, 512>(e, in, out, pin, pout, count, shift, mask, next_shift)
+                                   : launch_reorder_t<Key, true, false, false, 8, 512>(e, in, out, pin, pout, count, shift, mask, 0);
         }
     }
 #endif
     if (next_shift >= 0) {
-        return payload ? launch_reorder_t<Key, true, true>(e, in, out, pin, pout, count, shift, mask, next_shift, fold_paste)
-                       : launch_reorder_t<Key, false, true>(e, in, out, nullptr, nullptr, count, shift, mask, next_shift, fold_paste);
+        return payload ? launch_reorder_t<Key, true, true>(e, in, out, pin, pout, count, shift, mask, next_shift)
+                       : launch_reorder_t<Key, false, true>(e, in, out, nullptr, nullptr, count, shift, mask, next_shift);
     }
-    return payload ? launch_reorder_t<Key, true, false>(e, in, out, pin, pout, count, shift, mask, 0, fold_paste)
-                   : launch_reorder_t<Key, false, false>(e, in, out, nullptr, nullptr, count, shift, mask, 0, fold_paste);
+    return payload ? launch_reorder_t<Key, true, false>(e, in, out, pin, pout, count, shift, mask, 0)
+                   : launch_reorder_t<Key, false, false>(e, in, out, nullptr, nullptr, count, shift, mask, 0);
+}
+
+// The scatter kernels address their staging image from LDS address 0 (rsx::lds_store_at): true when the kernel declares no static LDS
+// in front of its dynamic array — checked here per kernel from its code-object attributes — and the device places a lone dynamic array
+// at 0 — checked by one probe launch per engine (lds_base_probe, rsx_create).  Either failing is a build / device the kernels were
+// not written for: rsx_create returns KERNEL_CREATION_FAILED (src/OperationStatus.h:12) instead of anything going wrong on the device.
+int no_static_lds(const void* fn, const char* name)
+{
+    hipFuncAttributes attr;
+    RSX_TRY(hipFuncGetAttributes(&attr, fn), RSX_KERNEL_CREATION_FAILED);
+    if (attr.sharedSizeBytes != 0) return fail(RSX_KERNEL_CREATION_FAILED, (std::string(name) + ": static LDS in front of the dynamic array (the kernels address LDS from 0)").c_str());
+    return RSX_OK;
+}
+
+int lds_base_probe(rsx_engine* e)
+{
+    uint32_t at = 1;
+    RSX_TRY(hipMemsetAsync(e->temp + 4, 0xFF, 4, e->stream), RSX_KERNEL_CREATION_FAILED);
+    hipLaunchKernelGGL(rsx::lds_base_probe_kernel, dim3(1), dim3(64), 256, e->stream, e->temp + 4);
+    RSX_TRY(hipGetLastError(), RSX_KERNEL_CREATION_FAILED);
+    RSX_TRY(hipMemcpyAsync(&at, e->temp + 4, 4, hipMemcpyDeviceToHost, e->stream), RSX_KERNEL_CREATION_FAILED);
+    RSX_TRY(hipStreamSynchronize(e->stream), RSX_KERNEL_CREATION_FAILED);
+    if (at != 0) return fail(RSX_KERNEL_CREATION_FAILED, "a kernel's dynamic LDS does not start at address 0 on this device");
+    return RSX_OK;
 }
 
 template <typename Key, bool PAYLOAD, bool LOOKAHEAD, bool RANGED = false, int KPT = kKeysPerThread, int THREADS = kTileThreads>
 int allow_lds()
 {
-    using L = rsx::ReorderLayout<Key, THREADS, KPT, (!RANGED && RSX_ALIAS_COUNTERS != 0)>;
-    RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder_kernel<Key, THREADS, KPT, PAYLOAD, LOOKAHEAD, RANGED>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L::BYTES) + (64 << 10)),
-            RSX_INITIALIZATION_FAILED);
-    return RSX_OK;
+    using L = rsx::ReorderLayout<Key, THREADS, KPT>;
+    const void* fn = reinterpret_cast<const void*>(&rsx::reorder_kernel<Key, THREADS, KPT, PAYLOAD, LOOKAHEAD, RANGED>);
+    RSX_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L::BYTES) + (64 << 10)), RSX_INITIALIZATION_FAILED);
+    return no_static_lds(fn, "reorder_kernel");
 }
 
 // One full pass chain on explicit buffers: histogram -> scan -> paste -> reorder.
@@ -542,8 +572,8 @@ int run_ranged_pass(rsx_engine* e, const void* in, void* out, const uint32_t* pi
     if ((rc = launch_histogram<Key, true>(e, in, count, shift, RSX_RADIX - 1, klo, kmul)) != RSX_OK) return rc;
     if ((rc = launch_scan(e, count)) != RSX_OK) return rc;
     if ((rc = launch_paste(e, count)) != RSX_OK) return rc;
-    if (pin && pout) return launch_reorder_t<Key, true, false, true>(e, in, out, pin, pout, count, shift, RSX_RADIX - 1, 0, false, klo, kmul);
-    return launch_reorder_t<Key, false, false, true>(e, in, out, nullptr, nullptr, count, shift, RSX_RADIX - 1, 0, false, klo, kmul);
+    if (pin && pout) return launch_reorder_t<Key, true, false, true>(e, in, out, pin, pout, count, shift, RSX_RADIX - 1, 0, klo, kmul);
+    return launch_reorder_t<Key, false, false, true>(e, in, out, nullptr, nullptr, count, shift, RSX_RADIX - 1, 0, klo, kmul);
 }
 
 constexpr int kRangeBlocks = 2048;
@@ -651,11 +681,11 @@ int sort_selfscan_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* e
         uint32_t* next = e->cnt3[(i + 1) % 3];
         int rc;
         if (e->has_payload) {
-            rc = last ? launch_reorder_t<Key, true, false, false, KPT>(e, in, out, pin, pout, count, shift, RSX_RADIX - 1, 0, false, Key{0}, Key{0}, 0, self, next)
-                      : launch_reorder_t<Key, true, true, false, KPT>(e, in, out, pin, pout, count, shift, RSX_RADIX - 1, shift + RSX_RADIX_BITS, false, Key{0}, Key{0}, 0, self, next);
+            rc = last ? launch_reorder_t<Key, true, false, false, KPT>(e, in, out, pin, pout, count, shift, RSX_RADIX - 1, 0, Key{0}, Key{0}, 0, self, next)
+                      : launch_reorder_t<Key, true, true, false, KPT>(e, in, out, pin, pout, count, shift, RSX_RADIX - 1, shift + RSX_RADIX_BITS, Key{0}, Key{0}, 0, self, next);
         } else {
-            rc = last ? launch_reorder_t<Key, false, false, false, KPT>(e, in, out, nullptr, nullptr, count, shift, RSX_RADIX - 1, 0, false, Key{0}, Key{0}, 0, self, next)
-                      : launch_reorder_t<Key, false, true, false, KPT>(e, in, out, nullptr, nullptr, count, shift, RSX_RADIX - 1, shift + RSX_RADIX_BITS, false, Key{0}, Key{0}, 0, self, next);
+            rc = last ? launch_reorder_t<Key, false, false, false, KPT>(e, in, out, nullptr, nullptr, count, shift, RSX_RADIX - 1, 0, Key{0}, Key{0}, 0, self, next)
+                      : launch_reorder_t<Key, false, true, false, KPT>(e, in, out, nullptr, nullptr, count, shift, RSX_RADIX - 1, shift + RSX_RADIX_BITS, Key{0}, Key{0}, 0, self, next);
         }
         if (rc != RSX_OK) return rc;
         in = out;
@@ -678,7 +708,7 @@ int sort_selfscan_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* e
 }
 
 #if RSX_TILE_THREADS == 256      // (the 8-bit kernels are written for 256-thread tiles: one thread per digit)
-// extra dynamic LDS of the default 8-bit scatter, by variant: 2 workgroups per CU instead of 3 for 64-bit elements (see rsx_engine::r8_extra_lds)
+// extra dynamic LDS of the 8-bit scatter, by variant: 2 workgroups per CU instead of 3 for 64-bit elements (see rsx_engine::r8_extra_lds)
 size_t r8_extra_lds_for(const rsx_engine* e, bool elem64, bool separate_payload)
 {
     if (e->r8_extra_lds >= 0) return static_cast<size_t>(e->r8_extra_lds);
@@ -688,14 +718,11 @@ size_t r8_extra_lds_for(const rsx_engine* e, bool elem64, bool separate_payload)
     // uint64 keys / packed uint32 key + payload: 45 KiB + 8 = two workgroups per CU (+10 % / +27 % on random keys, +15 % on Range), and the spread between
     // engines of one process — the "modes" of rounds 1-2 — shrinks from 7-11 % to 2 % (profiles/r03_modes_vs_workgroups_per_cu.txt).  uint64 keys with a payload
     // array likewise (six engines: 14.9-16.6 ms per sort at three, 14.4-14.8 at two), at the price of 9 % on constant data, which has nothing to merge
-    // (keys and payloads in one image, RSX_R8_MERGED_PAYLOAD: 62 KiB per workgroup = two per CU as it stands)
-    if (separate_payload) return RSX_R8_MERGED_PAYLOAD && !RSX_R8_PADDED_FINAL ? 0u : (16u << 10);
+    if (separate_payload) return 16u << 10;
     return 8u << 10;
 }
 
-constexpr size_t kTickets8Bytes = 8 * rsx::kNumXcd * sizeof(uint32_t);           // at most 8 byte passes (64-bit keys)
-
-// 512-thread workgroups for the default 8-bit scatter, by variant
+// 512-thread workgroups for the 8-bit scatter, by variant
 bool r8_wide_for(const rsx_engine* e, bool key64, bool has_payload)
 {
     if (e->r8_wide >= 0) return e->r8_wide != 0;
@@ -705,13 +732,20 @@ bool r8_wide_for(const rsx_engine* e, bool key64, bool has_payload)
     return key64 && !has_payload;
 }
 
-// workgroups per CU of the staying grid of the default 8-bit scatter (0 = one workgroup per tile), by variant
-int r8_stay_for(const rsx_engine* e, bool elem64, bool separate_payload)
+template <typename K, int THREADS, int KPT, bool PAYLOAD, bool PACKED32 = false>
+int allow_lds8(int extra)
 {
-    if (e->r8_stay >= 0) return e->r8_stay;
-    (void)elem64; (void)separate_payload;
-    return 0;
+    using L = rsx::Reorder8Layout<K, THREADS, KPT, PAYLOAD>;
+    const void* fn = reinterpret_cast<const void*>(&rsx::reorder8_kernel<K, THREADS, KPT, PAYLOAD, PACKED32>);
+    RSX_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L::BYTES) + extra), RSX_INITIALIZATION_FAILED);
+    return no_static_lds(fn, "reorder8_kernel");
 }
+
+#ifdef RSX_EXPERIMENTS
+template <typename Key> int ensure_radix8_experiments(rsx_engine* e, int extra);
+template <typename Key> bool launch_reorder8_experiment(rsx_engine* e, const void* in, void* out, const uint32_t* pin, uint32_t* pout, uint64_t count, const Grid& g,
+                                                        uint32_t chunk_groups, int shift, int byte_pass, bool first_of_chain, int* rc);
+#endif
 
 // The 8-bit chain's tables, allocated on first use — by sort_chain BEFORE any stream capture begins (an allocation inside
 // hipStreamBeginCapture invalidates the capture) and by rsx_set_option(RSX_OPT_RADIX_BITS, 8).  A call that failed half-way
@@ -720,7 +754,6 @@ template <typename Key>
 int ensure_radix8(rsx_engine* e)
 {
     if (e->radix8_ready) return RSX_OK;
-    using L = rsx::Reorder8Layout<Key, kTileThreads, kKeysPerThread>;
     const int extra = e->r8_extra_lds >= 0 ? static_cast<int>(e->r8_extra_lds) : (16 << 10);      // the most any variant asks for
     const size_t rows = static_cast<size_t>(e->ntiles(e->capacity)) * rsx::kRadix8 * 4;
     const size_t groups = ((e->ntiles(e->capacity) + rsx::kScan8Tiles - 1) / rsx::kScan8Tiles) * rsx::kRadix8 * 4;
@@ -729,200 +762,143 @@ int ensure_radix8(rsx_engine* e)
     if (!e->gsum8) RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->gsum8), groups), RSX_INITIALIZATION_FAILED);
     if (!e->csum8) RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->csum8), rsx::kScan8MaxChunks * rsx::kRadix8 * 4), RSX_INITIALIZATION_FAILED);
     if (!e->cbase8) RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->cbase8), rsx::kScan8MaxChunks * rsx::kRadix8 * 4), RSX_INITIALIZATION_FAILED);
-    if (!e->tickets8) RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->tickets8), kTickets8Bytes), RSX_INITIALIZATION_FAILED);
-    RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L::BYTES) + extra), RSX_INITIALIZATION_FAILED);
-    using LP = rsx::Reorder8Layout<Key, kTileThreads, kKeysPerThread, true>;          // with a separate payload array: keys and payloads share the image
-    RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(LP::BYTES) + extra), RSX_INITIALIZATION_FAILED);
-    RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8_stay_kernel<Key, kTileThreads, kKeysPerThread, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L::BYTES) + extra), RSX_INITIALIZATION_FAILED);
-    RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8_stay_kernel<Key, kTileThreads, kKeysPerThread, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(LP::BYTES) + extra), RSX_INITIALIZATION_FAILED);
-    {
-        using WK = rsx::Reorder8Layout<Key, 512, 8, false>;
-        using WP = rsx::Reorder8Layout<Key, 512, 8, true>;
-        RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8_kernel<Key, 512, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(WK::BYTES) + extra),
-                RSX_INITIALIZATION_FAILED);
-        RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8_kernel<Key, 512, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(WP::BYTES) + extra),
-                RSX_INITIALIZATION_FAILED);
-        if constexpr (sizeof(Key) == 4) {
-            using WX = rsx::Reorder8Layout<uint64_t, 512, 8, false>;
-            RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8_kernel<uint64_t, 512, 8, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(WX::BYTES) + extra),
-                    RSX_INITIALIZATION_FAILED);
-        }
+    int rc = allow_lds8<Key, kTileThreads, kKeysPerThread, false>(extra);
+    if (rc == RSX_OK) rc = allow_lds8<Key, kTileThreads, kKeysPerThread, true>(extra);
+    if (rc == RSX_OK) rc = allow_lds8<Key, 512, 8, false>(extra);
+    if (rc == RSX_OK) rc = allow_lds8<Key, 512, 8, true>(extra);
+    if constexpr (sizeof(Key) == 4) {          // uint32 key + payload as one 64-bit element
+        if (rc == RSX_OK) rc = allow_lds8<uint64_t, kTileThreads, kKeysPerThread, false, true>(extra);
+        if (rc == RSX_OK) rc = allow_lds8<uint64_t, 512, 8, false, true>(extra);
     }
-    constexpr int lds_v2k = static_cast<int>(rsx::Reorder8V2Layout<Key, kTileThreads, kKeysPerThread, false>::BYTES);
-    constexpr int lds_v2p = static_cast<int>(rsx::Reorder8V2Layout<Key, kTileThreads, kKeysPerThread, true>::BYTES);
-    RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8v2_kernel<Key, kTileThreads, kKeysPerThread, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_v2k),
-            RSX_INITIALIZATION_FAILED);
-    RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8v2_kernel<Key, kTileThreads, kKeysPerThread, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_v2p),
-            RSX_INITIALIZATION_FAILED);
-    if constexpr (sizeof(Key) == 4) {
-        constexpr int lds_packed = static_cast<int>(rsx::Reorder8Layout<uint64_t, kTileThreads, kKeysPerThread>::BYTES);
-        RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8_kernel<uint64_t, kTileThreads, kKeysPerThread, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_packed + extra),
-                RSX_INITIALIZATION_FAILED);
-        RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8_stay_kernel<uint64_t, kTileThreads, kKeysPerThread, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_packed + extra),
-                RSX_INITIALIZATION_FAILED);
-    }
-    constexpr int lds_v3k = static_cast<int>(rsx::Reorder8V3Layout<Key, kTileThreads, kKeysPerThread, false>::BYTES);
-    constexpr int lds_v3p = static_cast<int>(rsx::Reorder8V3Layout<Key, kTileThreads, kKeysPerThread, true>::BYTES);
-    RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8v3_kernel<Key, kTileThreads, kKeysPerThread, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_v3k),
-            RSX_INITIALIZATION_FAILED);
-    RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder8v3_kernel<Key, kTileThreads, kKeysPerThread, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_v3p),
-            RSX_INITIALIZATION_FAILED);
-    if (e->lds_atomics_ordered < 0) {
-        // kernel 3 ranks keys by the value a returning LDS atomic hands back and relies on lanes that meet on an address being served in
-        // ascending lane order: checked once per engine on the device it runs on (64 rounds of 16 instructions, patterns from all-equal
-        // to all-distinct); if it ever fails the engine keeps the two-round kernel
-        RSX_TRY(hipMemsetAsync(e->temp + 8, 0, 4, e->stream), RSX_INITIALIZATION_FAILED);
-        hipLaunchKernelGGL(rsx::lds_atomic_order_probe_kernel, dim3(1), dim3(256), 0, e->stream, e->temp + 8);
-        RSX_TRY(hipGetLastError(), RSX_INITIALIZATION_FAILED);
-        uint32_t bad = 1;
-        RSX_TRY(hipMemcpyAsync(&bad, e->temp + 8, 4, hipMemcpyDeviceToHost, e->stream), RSX_INITIALIZATION_FAILED);
-        RSX_TRY(hipStreamSynchronize(e->stream), RSX_INITIALIZATION_FAILED);
-        e->lds_atomics_ordered = bad == 0 ? 1 : 0;
-        if (bad) std::fprintf(stderr, "[radixsort_hip] LDS atomics do not return ranks in lane order on this device (%u mismatches): the 8-bit scatter keeps the two-round kernel\n", bad);
-    }
+#ifdef RSX_EXPERIMENTS
+    if (rc == RSX_OK) rc = ensure_radix8_experiments<Key>(e, extra);
+#endif
+    if (rc != RSX_OK) return rc;
     e->radix8_ready = true;
     return RSX_OK;
 }
+
+// One scatter launch of an 8-bit pass: by variant (keys only / separate payload array / uint32 key + payload packed into one 64-bit
+// element) on 256 x 16 or 512 x 8 threads x keys; the same 4096-key tiles and tables for all of them.
+template <typename Key>
+int launch_reorder8(rsx_engine* e, const void* in, void* out, const uint32_t* pin, uint32_t* pout, uint64_t count, const Grid& g, uint32_t chunk_groups, int shift)
+{
+    const Key flip = flip_mask<Key>(e);
+    const bool packed = sizeof(Key) == 4 && e->has_payload && e->r8_packed;
+    const bool wide = r8_wide_for(e, sizeof(Key) == 8, e->has_payload);
+    const size_t wide_extra = e->r8_extra_lds >= 0 ? static_cast<size_t>(e->r8_extra_lds) : 0;      // (57-62 KiB per workgroup: two per CU as they stand)
+    const dim3 grid(g.blocks);
+    // (dynamic LDS per variant, named here: template commas do not survive inside the launch macro)
+    constexpr size_t lds_packed = rsx::Reorder8Layout<uint64_t, kTileThreads, kKeysPerThread>::BYTES, lds_packed_wide = rsx::Reorder8Layout<uint64_t, 512, 8, false>::BYTES;
+    constexpr size_t lds_pay = rsx::Reorder8Layout<Key, kTileThreads, kKeysPerThread, true>::BYTES, lds_pay_wide = rsx::Reorder8Layout<Key, 512, 8, true>::BYTES;
+    constexpr size_t lds_keys = rsx::Reorder8Layout<Key, kTileThreads, kKeysPerThread>::BYTES, lds_keys_wide = rsx::Reorder8Layout<Key, 512, 8, false>::BYTES;
+    if (packed) {
+        // uint32 key + payload as one 64-bit element (rsx::reorder8_kernel<.., PACKED32>)
+        if (wide) {
+            hipLaunchKernelGGL((rsx::reorder8_kernel<uint64_t, 512, 8, false, true>), grid, dim3(512), lds_packed_wide + wide_extra, e->stream,
+                               static_cast<const uint64_t*>(in), static_cast<uint64_t*>(out), pin, pout, e->table8, e->gsum8, e->cbase8, chunk_groups,
+                               count, g.ntiles, g.tiles_per_xcd, g.remap, shift, static_cast<uint64_t>(flip));
+        } else {
+            hipLaunchKernelGGL((rsx::reorder8_kernel<uint64_t, kTileThreads, kKeysPerThread, false, true>), grid, dim3(kTileThreads),
+                               lds_packed + r8_extra_lds_for(e, true, false), e->stream,
+                               static_cast<const uint64_t*>(in), static_cast<uint64_t*>(out), pin, pout, e->table8, e->gsum8, e->cbase8, chunk_groups,
+                               count, g.ntiles, g.tiles_per_xcd, g.remap, shift, static_cast<uint64_t>(flip));
+        }
+    } else if (e->has_payload) {
+        if (wide) {
+            hipLaunchKernelGGL((rsx::reorder8_kernel<Key, 512, 8, true>), grid, dim3(512), lds_pay_wide + wide_extra, e->stream,
+                               static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->table8, e->gsum8, e->cbase8, chunk_groups,
+                               count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip);
+        } else {
+            hipLaunchKernelGGL((rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, true>), grid, dim3(kTileThreads),
+                               lds_pay + r8_extra_lds_for(e, sizeof(Key) == 8, true), e->stream,
+                               static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->table8, e->gsum8, e->cbase8, chunk_groups,
+                               count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip);
+        }
+    } else {
+        if (wide) {
+            hipLaunchKernelGGL((rsx::reorder8_kernel<Key, 512, 8, false>), grid, dim3(512), lds_keys_wide + wide_extra, e->stream,
+                               static_cast<const Key*>(in), static_cast<Key*>(out), nullptr, nullptr, e->table8, e->gsum8, e->cbase8, chunk_groups,
+                               count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip);
+        } else {
+            hipLaunchKernelGGL((rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, false>), grid, dim3(kTileThreads),
+                               lds_keys + r8_extra_lds_for(e, sizeof(Key) == 8, false), e->stream,
+                               static_cast<const Key*>(in), static_cast<Key*>(out), nullptr, nullptr, e->table8, e->gsum8, e->cbase8, chunk_groups,
+                               count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip);
+        }
+    }
+    RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
+    return RSX_OK;
+}
+
+// chunks of the second scan level for a table of `ngroups` scan groups
+struct Scan8Shape {
+    uint32_t ngroups, chunk_groups, nchunks;
+};
+Scan8Shape scan8_shape(uint32_t ntiles)
+{
+    Scan8Shape s;
+    s.ngroups = (ntiles + rsx::kScan8Tiles - 1) / rsx::kScan8Tiles;
+    s.chunk_groups = std::max<uint32_t>(64u, (s.ngroups + rsx::kScan8MaxChunks - 1) / rsx::kScan8MaxChunks);
+    s.nchunks = (s.ngroups + s.chunk_groups - 1) / s.chunk_groups;
+    return s;
+}
+
+// histogram8 -> scan8 (blocks, chunks[, top]) of one 8-bit pass: leaves table8 / gsum8 / cbase8 ready for the scatter
+template <typename Key>
+int launch_count8(rsx_engine* e, const void* in, uint64_t count, const Grid& g, const Scan8Shape& s, int shift)
+{
+    {
+        Bracket b(e, PH_HISTO);
+        hipLaunchKernelGGL((rsx::histogram8_kernel<Key, kTileThreads, kKeysPerThread>), dim3(g.blocks), dim3(kTileThreads), 0, e->stream,
+                           static_cast<const Key*>(in), e->counts8, count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip_mask<Key>(e));
+    }
+    {
+        Bracket b(e, PH_SCAN);
+        hipLaunchKernelGGL(rsx::scan8_blocks_kernel, dim3(s.ngroups), dim3(rsx::kRadix8), 0, e->stream, e->counts8, e->table8, e->gsum8, g.ntiles);
+    }
+    {
+        Bracket b(e, PH_SCAN);
+        if (s.nchunks == 1) {
+            hipLaunchKernelGGL(rsx::scan8_chunks_kernel<true>, dim3(1), dim3(rsx::kRadix8), 0, e->stream, e->gsum8, e->csum8, s.ngroups, s.chunk_groups, e->cbase8, e->temp);
+        } else {
+            hipLaunchKernelGGL(rsx::scan8_chunks_kernel<false>, dim3(s.nchunks), dim3(rsx::kRadix8), 0, e->stream, e->gsum8, e->csum8, s.ngroups, s.chunk_groups, e->cbase8, e->temp);
+            hipLaunchKernelGGL(rsx::scan8_top_kernel, dim3(1), dim3(rsx::kRadix8), 0, e->stream, e->csum8, e->cbase8, e->temp, s.nchunks);
+        }
+    }
+    RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
+    return RSX_OK;
+}
+
 // 8-bit digits: per pass histogram8 -> scan8 (two launches) -> reorder8, half as many passes.  Taken by the sort
 // chain when RSX_OPT_RADIX_BITS is 8 and the pass range [first_pass, last_pass) — counted in 4-bit passes, as
 // everywhere in this API — covers whole bytes.
 template <typename Key>
 int sort8_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext_perm, uint64_t count)
 {
-    using L = rsx::Reorder8Layout<Key, kTileThreads, kKeysPerThread>;
     const Grid g = grid_for(e, count);
-    const uint32_t ngroups = (g.ntiles + rsx::kScan8Tiles - 1) / rsx::kScan8Tiles;
-    const uint32_t chunk_groups = std::max<uint32_t>(64u, (ngroups + rsx::kScan8MaxChunks - 1) / rsx::kScan8MaxChunks);
-    const uint32_t nchunks = (ngroups + chunk_groups - 1) / chunk_groups;
+    const Scan8Shape s = scan8_shape(g.ntiles);
     if (!e->radix8_ready) return fail(RSX_INITIALIZATION_FAILED, "sort8_chain_enqueue: the 8-bit tables were not allocated (ensure_radix8)");
     const void* in = ext_keys ? ext_keys : e->keys[e->cur];
     const uint32_t* pin = e->has_payload ? (ext_keys ? ext_perm : e->perm[e->cur]) : nullptr;
     int dst = ext_keys ? e->cur : (e->cur ^ 1);
     Bracket whole(e, PH_TOTAL);
     e->counted_keys = nullptr;
-    const Key flip = flip_mask<Key>(e);
-    // kernel 1 as a staying grid (reorder8_stay_kernel): that many workgroups per CU draw tile tickets, which start from zero in every sort
-    const bool r8_packed = sizeof(Key) == 4 && e->has_payload && e->r8_packed;
-    const int stay = (e->reorder8_version == 1 || (e->reorder8_version == 3 && e->lds_atomics_ordered != 1))
-                         ? r8_stay_for(e, r8_packed || sizeof(Key) == 8, e->has_payload && !r8_packed) : 0;
-    const uint32_t stay_blocks = static_cast<uint32_t>(stay) * static_cast<uint32_t>(std::max(e->num_cus, static_cast<int>(rsx::kNumXcd))) / rsx::kNumXcd * rsx::kNumXcd;
-    const bool use_stay = stay > 0 && stay_blocks < g.blocks;
-    if (use_stay) RSX_TRY(hipMemsetAsync(e->tickets8, 0, kTickets8Bytes, e->stream), RSX_CALCULATION_FAILED);
     for (int pass = e->first_pass; pass < e->last_pass; pass += 2) {
         const bool to_caller = e->final_keys_out && pass + 2 == e->last_pass;
         void* out = to_caller ? e->final_keys_out : e->keys[dst];
         uint32_t* pout = e->has_payload ? (to_caller ? e->final_perm_out : e->perm[dst]) : nullptr;
         const int shift = pass * RSX_RADIX_BITS;
-        {
-            Bracket b(e, PH_HISTO);
-            hipLaunchKernelGGL((rsx::histogram8_kernel<Key, kTileThreads, kKeysPerThread>), dim3(g.blocks), dim3(kTileThreads), 0, e->stream,
-                               static_cast<const Key*>(in), e->counts8, count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip);
-        }
-        {
-            Bracket b(e, PH_SCAN);
-            hipLaunchKernelGGL(rsx::scan8_blocks_kernel, dim3(ngroups), dim3(rsx::kRadix8), 0, e->stream, e->counts8, e->table8, e->gsum8, g.ntiles);
-        }
-        {
-            Bracket b(e, PH_SCAN);
-            if (nchunks == 1) {
-                hipLaunchKernelGGL(rsx::scan8_chunks_kernel<true>, dim3(1), dim3(rsx::kRadix8), 0, e->stream, e->gsum8, e->csum8, ngroups, chunk_groups, e->cbase8, e->temp);
-            } else {
-                hipLaunchKernelGGL(rsx::scan8_chunks_kernel<false>, dim3(nchunks), dim3(rsx::kRadix8), 0, e->stream, e->gsum8, e->csum8, ngroups, chunk_groups, e->cbase8, e->temp);
-                hipLaunchKernelGGL(rsx::scan8_top_kernel, dim3(1), dim3(rsx::kRadix8), 0, e->stream, e->csum8, e->cbase8, e->temp, nchunks);
-            }
-        }
+        int rc = launch_count8<Key>(e, in, count, g, s, shift);
+        if (rc != RSX_OK) return rc;
         {
             Bracket b(e, PH_REORDER);
-            constexpr size_t lds_v2k = rsx::Reorder8V2Layout<Key, kTileThreads, kKeysPerThread, false>::BYTES;
-            constexpr size_t lds_v2p = rsx::Reorder8V2Layout<Key, kTileThreads, kKeysPerThread, true>::BYTES;
-            constexpr size_t lds_v3k = rsx::Reorder8V3Layout<Key, kTileThreads, kKeysPerThread, false>::BYTES;
-            constexpr size_t lds_v3p = rsx::Reorder8V3Layout<Key, kTileThreads, kKeysPerThread, true>::BYTES;
-            if (e->reorder8_version == 3 && e->lds_atomics_ordered == 1) {
-                if (e->has_payload) {
-                    hipLaunchKernelGGL((rsx::reorder8v3_kernel<Key, kTileThreads, kKeysPerThread, true>), dim3(g.blocks), dim3(kTileThreads), lds_v3p, e->stream,
-                                       static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->table8, e->gsum8, e->cbase8, chunk_groups,
-                                       count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip);
-                } else {
-                    hipLaunchKernelGGL((rsx::reorder8v3_kernel<Key, kTileThreads, kKeysPerThread, false>), dim3(g.blocks), dim3(kTileThreads), lds_v3k, e->stream,
-                                       static_cast<const Key*>(in), static_cast<Key*>(out), nullptr, nullptr, e->table8, e->gsum8, e->cbase8, chunk_groups,
-                                       count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip);
-                }
-            } else if (e->reorder8_version == 2) {
-                if (e->has_payload) {
-                    hipLaunchKernelGGL((rsx::reorder8v2_kernel<Key, kTileThreads, kKeysPerThread, true>), dim3(g.blocks), dim3(kTileThreads),
-                                       lds_v2p, e->stream,
-                                       static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->table8, e->gsum8, e->cbase8, chunk_groups,
-                                       count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip);
-                } else {
-                    hipLaunchKernelGGL((rsx::reorder8v2_kernel<Key, kTileThreads, kKeysPerThread, false>), dim3(g.blocks), dim3(kTileThreads),
-                                       lds_v2k, e->stream,
-                                       static_cast<const Key*>(in), static_cast<Key*>(out), nullptr, nullptr, e->table8, e->gsum8, e->cbase8, chunk_groups,
-                                       count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip);
-                }
-            } else {
-                // kernel 1.  stay > 0: a grid of that many workgroups per CU walks the tiles and prefetches (reorder8_stay_kernel)
-                const bool packed = r8_packed;
-                const bool wide = !use_stay && r8_wide_for(e, sizeof(Key) == 8, e->has_payload);
-                const size_t wide_extra = e->r8_extra_lds >= 0 ? static_cast<size_t>(e->r8_extra_lds) : 0;      // (57-62 KiB per workgroup: two per CU as they stand)
-                constexpr size_t lds_wide_packed = rsx::Reorder8Layout<uint64_t, 512, 8, false>::BYTES;
-                constexpr size_t lds_wide_keys = rsx::Reorder8Layout<Key, 512, 8, false>::BYTES;
-                constexpr size_t lds_wide_pay = rsx::Reorder8Layout<Key, 512, 8, true>::BYTES;
-                const dim3 grid(use_stay ? stay_blocks : g.blocks);
-                if (packed) {
-                    // uint32 key + payload as one 64-bit element (rsx::reorder8_kernel<.., PACKED32>)
-                    constexpr size_t lds_packed = rsx::Reorder8Layout<uint64_t, kTileThreads, kKeysPerThread>::BYTES;
-                    const size_t lds = lds_packed + r8_extra_lds_for(e, true, false);
-                    if (wide) {
-                        hipLaunchKernelGGL((rsx::reorder8_kernel<uint64_t, 512, 8, false, true>), grid, dim3(512), lds_wide_packed + wide_extra, e->stream,
-                                           static_cast<const uint64_t*>(in), static_cast<uint64_t*>(out), pin, pout, e->table8, e->gsum8, e->cbase8, chunk_groups,
-                                           count, g.ntiles, g.tiles_per_xcd, g.remap, shift, static_cast<uint64_t>(flip));
-                    } else if (use_stay) {
-                        hipLaunchKernelGGL((rsx::reorder8_stay_kernel<uint64_t, kTileThreads, kKeysPerThread, false, true>), grid, dim3(kTileThreads), lds, e->stream,
-                                           static_cast<const uint64_t*>(in), static_cast<uint64_t*>(out), pin, pout, e->table8, e->gsum8, e->cbase8, chunk_groups,
-                                           count, g.ntiles, g.tiles_per_xcd, g.remap, shift, static_cast<uint64_t>(flip), e->tickets8 + static_cast<size_t>(pass / 2) * rsx::kNumXcd);
-                    } else {
-                        hipLaunchKernelGGL((rsx::reorder8_kernel<uint64_t, kTileThreads, kKeysPerThread, false, true>), grid, dim3(kTileThreads), lds, e->stream,
-                                           static_cast<const uint64_t*>(in), static_cast<uint64_t*>(out), pin, pout, e->table8, e->gsum8, e->cbase8, chunk_groups,
-                                           count, g.ntiles, g.tiles_per_xcd, g.remap, shift, static_cast<uint64_t>(flip));
-                    }
-                } else if (e->has_payload) {
-                    const size_t lds = rsx::Reorder8Layout<Key, kTileThreads, kKeysPerThread, true>::BYTES + r8_extra_lds_for(e, sizeof(Key) == 8, true);
-                    if (wide) {
-                        hipLaunchKernelGGL((rsx::reorder8_kernel<Key, 512, 8, true>), grid, dim3(512), lds_wide_pay + wide_extra, e->stream,
-                                           static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->table8, e->gsum8, e->cbase8, chunk_groups,
-                                           count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip);
-                    } else if (use_stay) {
-                        hipLaunchKernelGGL((rsx::reorder8_stay_kernel<Key, kTileThreads, kKeysPerThread, true>), grid, dim3(kTileThreads), lds, e->stream,
-                                           static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->table8, e->gsum8, e->cbase8, chunk_groups,
-                                           count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip, e->tickets8 + static_cast<size_t>(pass / 2) * rsx::kNumXcd);
-                    } else {
-                        hipLaunchKernelGGL((rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, true>), grid, dim3(kTileThreads), lds, e->stream,
-                                           static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->table8, e->gsum8, e->cbase8, chunk_groups,
-                                           count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip);
-                    }
-                } else {
-                    const size_t lds = L::BYTES + r8_extra_lds_for(e, sizeof(Key) == 8, false);
-                    if (wide) {
-                        hipLaunchKernelGGL((rsx::reorder8_kernel<Key, 512, 8, false>), grid, dim3(512), lds_wide_keys + wide_extra, e->stream,
-                                           static_cast<const Key*>(in), static_cast<Key*>(out), nullptr, nullptr, e->table8, e->gsum8, e->cbase8, chunk_groups,
-                                           count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip);
-                    } else if (use_stay) {
-                        hipLaunchKernelGGL((rsx::reorder8_stay_kernel<Key, kTileThreads, kKeysPerThread, false>), grid, dim3(kTileThreads), lds, e->stream,
-                                           static_cast<const Key*>(in), static_cast<Key*>(out), nullptr, nullptr, e->table8, e->gsum8, e->cbase8, chunk_groups,
-                                           count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip, e->tickets8 + static_cast<size_t>(pass / 2) * rsx::kNumXcd);
-                    } else {
-                        hipLaunchKernelGGL((rsx::reorder8_kernel<Key, kTileThreads, kKeysPerThread, false>), grid, dim3(kTileThreads), lds, e->stream,
-                                           static_cast<const Key*>(in), static_cast<Key*>(out), nullptr, nullptr, e->table8, e->gsum8, e->cbase8, chunk_groups,
-                                           count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip);
-                    }
-                }
-            }
+#ifdef RSX_EXPERIMENTS
+            if (!launch_reorder8_experiment<Key>(e, in, out, pin, pout, count, g, s.chunk_groups, shift, pass / 2, pass == e->first_pass, &rc))
+#endif
+                rc = launch_reorder8<Key>(e, in, out, pin, pout, count, g, s.chunk_groups, shift);
         }
-        RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
+        if (rc != RSX_OK) return rc;
         e->last_in = in;
         e->last_shift = shift + RSX_RADIX_BITS;       // (the reference-geometry diagnostics are those of 4-bit passes; not meaningful here)
         in = out;
@@ -945,88 +921,10 @@ int sort8_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext
 
 #endif
 
-// Reorder launch with the table scan inside it (rsx::InlineScanArgs): LOOKAHEAD counts the next pass into `next_counts`.
-template <typename Key, bool PAYLOAD, bool LOOKAHEAD>
-int launch_reorder_inline(rsx_engine* e, const void* in, void* out, const uint32_t* pin, uint32_t* pout, uint64_t count, int shift, int next_shift,
-                          uint32_t* next_counts, const rsx::InlineScanArgs& iscan)
-{
-    using L = rsx::ReorderLayout<Key, kTileThreads, kKeysPerThread, (RSX_ALIAS_COUNTERS != 0)>;
-    static_assert(L::BYTES >= sizeof(rsx::FusedScanLds), "the scan's scratch lies over the reorder's dynamic LDS");
-    static bool allowed = false;       // (per instantiation)
-    if (!allowed) {
-        RSX_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rsx::reorder_kernel<Key, kTileThreads, kKeysPerThread, PAYLOAD, LOOKAHEAD, false, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L::BYTES)), RSX_INITIALIZATION_FAILED);
-        allowed = true;
-    }
-    const Grid g = grid_for(e, count);
-    e->last_in = in;
-    e->last_shift = shift;
-    Bracket b(e, PH_REORDER);
-    hipLaunchKernelGGL((rsx::reorder_kernel<Key, kTileThreads, kKeysPerThread, PAYLOAD, LOOKAHEAD, false, true>), dim3(g.blocks), dim3(kTileThreads), L::BYTES, e->stream,
-                       static_cast<const Key*>(in), static_cast<Key*>(out), pin, pout, e->table, count, g.ntiles, g.tiles_per_xcd, g.remap, shift, flip_mask<Key>(e),
-                       static_cast<uint32_t>(RSX_RADIX - 1), next_counts, next_shift, static_cast<const uint32_t*>(nullptr), Key{0}, Key{0}, split_set<Key>(e, 0),
-                       rsx::SelfScanArgs{nullptr, nullptr, nullptr}, rsx::PeerArgs{nullptr, nullptr}, iscan);
-    RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
-    return RSX_OK;
-}
-
-// Mid-size tables (beyond the self-scan, at most inline_scan_max_groups scan groups): one histogram launch, then ONE launch per pass —
-// the first workgroups of every reorder launch scan the pass's table before they turn to their own tiles (rsx::InlineScanArgs), so the
-// chain is passes + 1 dependent launches instead of 2 passes + 1.  Two count buffers alternate between "scanned (and zeroed) by this
-// launch" and "filled by this launch's look-ahead".
-template <typename Key>
-int sort_inline_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext_perm, uint64_t count)
-{
-    const uint32_t ntiles = static_cast<uint32_t>(e->ntiles(count));
-    const uint32_t ngroups = (ntiles + rsx::kScanTiles - 1) / rsx::kScanTiles;
-    const void* in = ext_keys ? ext_keys : e->keys[e->cur];
-    const uint32_t* pin = e->has_payload ? (ext_keys ? ext_perm : e->perm[e->cur]) : nullptr;
-    int dst = ext_keys ? e->cur : (e->cur ^ 1);
-    Bracket whole(e, PH_TOTAL);
-    const size_t rows = static_cast<size_t>(ntiles) * RSX_RADIX * 4;
-    RSX_TRY(hipMemsetAsync(e->counts_next, 0, rows, e->stream), RSX_CALCULATION_FAILED);      // (a sort that failed midway may have left counts)
-    RSX_TRY(hipMemsetAsync(e->counts_next2, 0, rows, e->stream), RSX_CALCULATION_FAILED);
-    int rc = launch_histogram<Key>(e, in, count, e->first_pass * RSX_RADIX_BITS, RSX_RADIX - 1);
-    if (rc != RSX_OK) return rc;
-    uint32_t* bufs[2] = {e->counts_next, e->counts_next2};
-    int filled = 1;                      // bufs[filled] holds the counts the NEXT launch scans (none before the first pass); its look-ahead fills the other
-    for (int pass = e->first_pass; pass < e->last_pass; ++pass) {
-        const bool first = pass == e->first_pass, last = pass + 1 == e->last_pass;
-        const bool to_caller = e->final_keys_out && last;
-        void* out = to_caller ? e->final_keys_out : e->keys[dst];
-        uint32_t* pout = e->has_payload ? (to_caller ? e->final_perm_out : e->perm[dst]) : nullptr;
-        const int shift = pass * RSX_RADIX_BITS;
-        if (++e->scan_epoch == 0) e->scan_epoch = 1;
-        const rsx::InlineScanArgs iscan{e->gsums, e->globsum2, e->temp, bufs[filled], e->scan_ready, e->scan_timeout, e->scan_epoch, ngroups, first ? 0 : 1};
-        uint32_t* next = bufs[filled ^ 1];
-        if (e->has_payload) {
-            rc = last ? launch_reorder_inline<Key, true, false>(e, in, out, pin, pout, count, shift, 0, next, iscan)
-                      : launch_reorder_inline<Key, true, true>(e, in, out, pin, pout, count, shift, shift + RSX_RADIX_BITS, next, iscan);
-        } else {
-            rc = last ? launch_reorder_inline<Key, false, false>(e, in, out, nullptr, nullptr, count, shift, 0, next, iscan)
-                      : launch_reorder_inline<Key, false, true>(e, in, out, nullptr, nullptr, count, shift, shift + RSX_RADIX_BITS, next, iscan);
-        }
-        if (rc != RSX_OK) return rc;
-        filled ^= 1;
-        in = out;
-        pin = pout;
-        dst ^= 1;
-    }
-    e->counted_keys = nullptr;
-    e->globsum_live = e->globsum2;
-    e->table_valid = true;
-    e->globsum_valid = true;
-    if (in == e->keys[0] || in == e->keys[1]) e->cur = (in == e->keys[0]) ? 0 : 1;
-    e->result_external = e->final_keys_out != nullptr;
-    if (e->final_keys_out) {
-        e->result_keys = e->final_keys_out;
-        e->result_perm = e->has_payload ? e->final_perm_out : nullptr;
-    } else {
-        e->result_keys = e->keys[e->cur];
-        e->result_perm = e->has_payload ? e->perm[e->cur] : nullptr;
-    }
-    return RSX_OK;
-}
+#ifdef RSX_EXPERIMENTS
+template <typename Key> int sort_inline_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext_perm, uint64_t count);
+bool inline_scan_takes(const rsx_engine* e, uint64_t count);
+#endif
 
 template <typename Key>
 int sort_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext_perm, uint64_t count)
@@ -1062,20 +960,12 @@ int sort_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext_
         return sort_tile_enqueue<Key>(e, ext_keys, ext_perm, count);
     }
 #endif
-    if (e->self_scan && e->lookahead && !e->fold_paste && count > static_cast<uint64_t>(kTileKeys) && e->ntiles(count) <= e->self_scan_max && e->first_pass < e->last_pass) {
+    if (e->self_scan && e->lookahead && count > static_cast<uint64_t>(kTileKeys) && e->ntiles(count) <= e->self_scan_max && e->first_pass < e->last_pass) {
         if (count <= e->small_tile_max_keys) return sort_selfscan_enqueue<Key, kSmallKeysPerThread>(e, ext_keys, ext_perm, count);
         return sort_selfscan_enqueue<Key>(e, ext_keys, ext_perm, count);
     }
-#if RSX_PRODUCT_SHAPE
-    {
-        const uint32_t groups = static_cast<uint32_t>((e->ntiles(count) + rsx::kScanTiles - 1) / rsx::kScanTiles);
-        // (profile mode 1 keeps the separate scan launches: timeScan / timePaste would otherwise be empty; a captured graph would replay a stale epoch)
-        if (e->inline_scan && e->lookahead && e->fused_scan && !e->fold_paste && !e->use_graph && e->profile != 1 && e->scan_zeroes && count > 0 &&
-            e->first_pass < e->last_pass && e->ntiles(count) > static_cast<uint64_t>(rsx::kSmallScanMaxTiles) &&
-            groups <= std::min(e->inline_scan_max_groups, e->fused_scan_limit)) {
-            return sort_inline_enqueue<Key>(e, ext_keys, ext_perm, count);
-        }
-    }
+#if defined(RSX_EXPERIMENTS) && RSX_PRODUCT_SHAPE
+    if (inline_scan_takes(e, count)) return sort_inline_enqueue<Key>(e, ext_keys, ext_perm, count);
 #endif
     // Ping-pong.  With external input the first pass reads the caller's buffer (never
     // written) and the chain continues inside the engine's two buffers.
@@ -1102,20 +992,14 @@ int sort_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext_
             rc = first ? launch_histogram<Key>(e, in, count, shift, RSX_RADIX - 1) : RSX_OK;
             bool pasted = false;
             if (rc == RSX_OK) pasted = launch_scan_small(e, count, /*from_counts=*/!first, &rc);
-            if (rc == RSX_OK && !pasted && !e->fold_paste) pasted = launch_scan_fused(e, count, /*from_counts=*/!first, &rc);
-            const bool merged = e->paste_scan && !e->fold_paste;     // scan #2 inside the paste launch
+            if (rc == RSX_OK && !pasted) pasted = launch_scan_fused(e, count, /*from_counts=*/!first, &rc);
+            const bool merged = e->paste_scan != 0;                  // scan #2 inside the paste launch
             if (rc == RSX_OK && !pasted) rc = launch_scan(e, count, /*from_counts=*/!first, /*scan_level2=*/!merged);
             // small tables were scanned and pasted in one launch; otherwise the paste kernel runs
-            // (RSX_FOLD_PASTE=1 lets the reorder add globsum[group] itself instead — measured slower;
-            // the last pass always pastes so that a downloaded table is the global prefix in any mode)
             const bool last = pass + 1 == e->last_pass;
-            const bool fold = e->fold_paste && !last && !pasted;
-            if (rc == RSX_OK && !fold && !pasted) rc = merged ? launch_paste_scan(e, count) : launch_paste(e, count);
+            if (rc == RSX_OK && !pasted) rc = merged ? launch_paste_scan(e, count) : launch_paste(e, count);
             const int next_shift = last ? -1 : shift + RSX_RADIX_BITS;
-            if (rc == RSX_OK && !last && !e->scan_zeroes) {
-                if (hipMemsetAsync(e->counts_next, 0, static_cast<size_t>(e->ntiles(count)) * RSX_RADIX * 4, e->stream) != hipSuccess) rc = RSX_CALCULATION_FAILED;
-            }
-            if (rc == RSX_OK) rc = launch_reorder<Key>(e, in, out, pin, pout, count, shift, RSX_RADIX - 1, next_shift, fold);
+            if (rc == RSX_OK) rc = launch_reorder<Key>(e, in, out, pin, pout, count, shift, RSX_RADIX - 1, next_shift);
         }
         if (rc != RSX_OK) return rc;
         in = out;
@@ -1162,7 +1046,7 @@ int sort_chain(rsx_engine* e, const void* ext_keys, const uint32_t* ext_perm, ui
     key.cur = e->cur;
     key.first = e->first_pass;
     key.last = e->last_pass;
-    key.flags = (e->lookahead ? 1 : 0) | (e->xcd_remap ? 2 : 0) | (e->fold_paste ? 4 : 0) | (e->scan_zeroes ? 8 : 0) | (e->small_scan ? 16 : 0);
+    key.flags = (e->lookahead ? 1 : 0) | (e->xcd_remap ? 2 : 0) | (e->small_scan ? 16 : 0);
     key.options_epoch = e->options_epoch;
     key.stream = e->stream;
     for (const GraphEntry& g : e->graphs) {
@@ -1254,87 +1138,71 @@ int bind_device(const rsx_engine* e, int status)
 }
 
 // ---- large-buffer allocation ----------------------------------------------------------------------------------------------
-hipError_t big_alloc(rsx_engine* e, void** out, size_t bytes)
+#ifdef RSX_EXPERIMENTS
+hipError_t big_alloc(rsx_engine* e, void** out, size_t bytes);       // capi_experiments.inc: optionally VMM chunks mapped in a shuffled order
+bool big_free(rsx_engine* e, void* p);
+#else
+hipError_t big_alloc(rsx_engine*, void** out, size_t bytes)
 {
     *out = nullptr;
-    rsx_engine::BigBuf b;
-    if (e->alloc_mode == 0 || bytes < (64u << 20)) {
-        const hipError_t err = hipMalloc(&b.base, bytes);
-        if (err != hipSuccess) return err;
-        b.size = bytes;
-        e->big.push_back(b);
-        *out = b.base;
-        return hipSuccess;
-    }
-    hipMemAllocationProp prop = {};
-    prop.type = hipMemAllocationTypePinned;
-    prop.location.type = hipMemLocationTypeDevice;
-    prop.location.id = e->device;
-    size_t gran = 0;
-    hipError_t err = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended);
-    if (err != hipSuccess) return err;
-    // chunks of at least 2 MiB and at most 1024 of them per buffer: the first version took the recommended granularity as it came
-    // (small on this stack) and spent minutes creating and mapping chunks (profiles/r03_fault_vmm_alloc_silence.txt)
-    size_t chunk = e->alloc_chunk ? e->alloc_chunk : (static_cast<size_t>(32) << 20);
-    chunk = std::max(chunk, static_cast<size_t>(2) << 20);
-    chunk = std::max(chunk, (bytes + 1023) / 1024);
-    chunk = (chunk + gran - 1) / gran * gran;
-    const size_t nchunks = (bytes + chunk - 1) / chunk;
-    if (std::getenv("RSX_DEBUG_ALLOC")) std::fprintf(stderr, "[radixsort_hip] big_alloc: %zu bytes as %zu chunks of %zu (granularity %zu), mode %d\n", bytes, nchunks, chunk, gran, e->alloc_mode);
-    b.size = nchunks * chunk;
-    if ((err = hipMemAddressReserve(&b.base, b.size, chunk, nullptr, 0)) != hipSuccess) return err;
-    auto undo = [&](hipError_t why) {
-        for (auto h : b.chunks) (void)hipMemRelease(h);
-        (void)hipMemAddressFree(b.base, b.size);
-        return why;
-    };
-    for (size_t i = 0; i < nchunks; ++i) {
-        hipMemGenericAllocationHandle_t h;
-        if ((err = hipMemCreate(&h, chunk, &prop, 0)) != hipSuccess) return undo(err);
-        b.chunks.push_back(h);
-    }
-    std::vector<size_t> order(nchunks);
-    for (size_t i = 0; i < nchunks; ++i) order[i] = i;
-    if (e->alloc_mode == 2) {
-        // a fixed pseudo-random permutation (xorshift; the same for every buffer of the same length: reproducible runs)
-        unsigned long long x = 0x9E3779B97F4A7C15ull ^ (nchunks * 0x100000001B3ull);
-        for (size_t i = nchunks - 1; i > 0; --i) {
-            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
-            std::swap(order[i], order[static_cast<size_t>(x % (i + 1))]);
-        }
-    }
-    for (size_t i = 0; i < nchunks; ++i) {
-        if ((err = hipMemMap(static_cast<char*>(b.base) + i * chunk, chunk, 0, b.chunks[order[i]], 0)) != hipSuccess) {
-            if (i) (void)hipMemUnmap(b.base, i * chunk);
-            return undo(err);
-        }
-    }
-    hipMemAccessDesc acc = {};
-    acc.location.type = hipMemLocationTypeDevice;
-    acc.location.id = e->device;
-    acc.flags = hipMemAccessFlagsProtReadWrite;
-    if ((err = hipMemSetAccess(b.base, b.size, &acc, 1)) != hipSuccess) {
-        (void)hipMemUnmap(b.base, b.size);
-        return undo(err);
-    }
-    e->big.push_back(b);
-    *out = b.base;
-    return hipSuccess;
+    return hipMalloc(out, bytes);
 }
 
-bool big_free(rsx_engine* e, void* p)
+bool big_free(rsx_engine*, void* p)
 {
-    if (!p) return true;
-    for (size_t i = 0; i < e->big.size(); ++i) {
-        if (e->big[i].base != p) continue;
-        rsx_engine::BigBuf b = e->big[i];
-        e->big.erase(e->big.begin() + static_cast<long>(i));
-        if (b.chunks.empty()) return hipFree(p) == hipSuccess;
-        bool ok = hipMemUnmap(b.base, b.size) == hipSuccess;
-        for (auto h : b.chunks) ok = (hipMemRelease(h) == hipSuccess) && ok;
-        return (hipMemAddressFree(b.base, b.size) == hipSuccess) && ok;
+    return !p || hipFree(p) == hipSuccess;
+}
+#endif
+
+#ifdef RSX_EXPERIMENTS
+#include "capi_experiments.inc"
+#endif
+
+// ---- environment --------------------------------------------------------------------------------------------------------------
+// Every environment variable the library reads, parsed ONCE per engine at rsx_create (rsx_set_option overrides afterwards where an
+// option exists).  They select between code paths that give identical results; defaults are the measured policies.
+struct EnvKnob {
+    const char* name;
+    const char* meaning;
+    void (*apply)(rsx_engine* e, const char* value);
+};
+constexpr long kb_or_policy(const char* v, int max_kb)
+{
+    return std::atoi(v) < 0 ? -1L : static_cast<long>(std::min(max_kb, std::atoi(v))) * 1024;
+}
+const EnvKnob kEnvKnobs[] = {
+    {"RSX_XCD_REMAP", "0: workgroup b takes tile b (default 1: XCD-contiguous tile ranges)", [](rsx_engine* e, const char* v) { e->xcd_remap = std::atoi(v) != 0; }},
+    {"RSX_XCD_PHASE", "tiles by which consecutive XCDs enter their range staggered (-1: an eighth of a range)", [](rsx_engine* e, const char* v) { e->xcd_phase = std::atoll(v); }},
+    {"RSX_LOOKAHEAD", "0: every pass runs histogram -> scan -> paste -> reorder (default 1: RSX_OPT_LOOKAHEAD)", [](rsx_engine* e, const char* v) { e->lookahead = std::atoi(v) != 0; }},
+    {"RSX_GRAPH", "1: small sorts replay a captured hipGraph (RSX_OPT_GRAPH, default 0)", [](rsx_engine* e, const char* v) { e->use_graph = std::atoi(v) != 0; }},
+    {"RSX_SMALL_SCAN", "0: no one-workgroup table scan (RSX_OPT_SMALL_SCAN)", [](rsx_engine* e, const char* v) { e->small_scan = std::atoi(v) != 0; }},
+    {"RSX_TILE_SORT", "0: no one-launch sort of inputs up to one tile (RSX_OPT_TILE_SORT)", [](rsx_engine* e, const char* v) { e->tile_sort = std::atoi(v) != 0; }},
+    {"RSX_SELF_SCAN", "0: small tables get scan launches (RSX_OPT_SELF_SCAN)", [](rsx_engine* e, const char* v) { e->self_scan = std::atoi(v) != 0; }},
+    {"RSX_SELF_SCAN_MAX", "largest table, in tiles, of the self-scan chain (RSX_OPT_SELF_SCAN_MAX_TILES)",
+     [](rsx_engine* e, const char* v) { e->self_scan_max = std::min<uint32_t>(static_cast<uint32_t>(std::atoi(v)), rsx::kSelfScanMaxTiles); }},
+    {"RSX_SMALL_TILE_MAX_KEYS", "self-scan sorts up to this many keys use 1024-key tiles (RSX_OPT_SMALL_TILE_MAX_KEYS)",
+     [](rsx_engine* e, const char* v) { e->small_tile_max_keys = std::min<uint64_t>(std::strtoull(v, nullptr, 10), static_cast<uint64_t>(rsx::kSelfScanMaxTiles) * kTileThreads * kSmallKeysPerThread); }},
+    {"RSX_PASTE_SCAN", "0: scan #2 gets a launch of its own in the two-launch table scan", [](rsx_engine* e, const char* v) { e->paste_scan = std::atoi(v) != 0; }},
+    {"RSX_FUSED_SCAN", "0: never the one-launch table scan (RSX_OPT_FUSED_SCAN)", [](rsx_engine* e, const char* v) { e->fused_scan = std::atoi(v) != 0; }},
+    {"RSX_RADIX_BITS", "8: byte-wide passes in the sort chain (RSX_OPT_RADIX_BITS)", [](rsx_engine* e, const char* v) { e->radix_bits = std::atoi(v) == 8 ? 8 : 4; }},
+    {"RSX_RADIX8_MIN_KEYS", "8-bit passes only above this many keys (default 2^19)", [](rsx_engine* e, const char* v) { e->radix8_min_keys = std::max<uint64_t>(std::strtoull(v, nullptr, 10), kTileKeys); }},
+    {"RSX_REORDER_EXTRA_LDS_KB", "unused dynamic LDS per 4-bit scatter workgroup = fewer per CU (-1: per-variant policy)", [](rsx_engine* e, const char* v) { e->reorder_extra_lds = kb_or_policy(v, 64); }},
+    {"RSX_REORDER_WIDE", "4-bit scatter of 64-bit keys + payload on 512 x 8 (0 / 1, -1: policy = on)", [](rsx_engine* e, const char* v) { e->reorder_wide = std::max(-1, std::min(1, std::atoi(v))); }},
+    {"RSX_R8_EXTRA_LDS_KB", "the same for the 8-bit scatter (-1: per-variant policy)", [](rsx_engine* e, const char* v) { e->r8_extra_lds = kb_or_policy(v, 96); }},
+    {"RSX_R8_PACKED", "0: uint32 key and payload travel apart through the 8-bit scatter (default 1: one 64-bit element)", [](rsx_engine* e, const char* v) { e->r8_packed = std::atoi(v) != 0; }},
+    {"RSX_R8_WIDE", "8-bit scatter on 512 x 8 (0 / 1, -1: policy = 64-bit keys without payload)", [](rsx_engine* e, const char* v) { e->r8_wide = std::max(-1, std::min(1, std::atoi(v))); }},
+#ifdef RSX_EXPERIMENTS
+    {"RSX_ALLOC_MODE", "experiments: key buffers as VMM chunks mapped in creation (1) or shuffled (2) order", [](rsx_engine* e, const char* v) { e->alloc_mode = std::max(0, std::min(2, std::atoi(v))); }},
+    {"RSX_ALLOC_CHUNK_MB", "experiments: chunk size of RSX_ALLOC_MODE", [](rsx_engine* e, const char* v) { e->alloc_chunk = static_cast<size_t>(std::max(0, std::atoi(v))) << 20; }},
+#endif
+};
+// (RSX_FUSED_SCAN_MAX_GROUPS is applied where the occupancy query has produced its bound; RSX_DEBUG_PTRS prints the buffer addresses)
+
+void apply_environment(rsx_engine* e)
+{
+    for (const EnvKnob& k : kEnvKnobs) {
+        if (const char* v = std::getenv(k.name)) k.apply(e, v);
     }
-    return hipFree(p) == hipSuccess;
 }
 
 }  // namespace
@@ -1399,33 +1267,7 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
     e->n = 0;
     e->last_pass = static_cast<int>(e->passes());
     for (auto& s : e->stats) stat_reset(s);
-    if (const char* env = std::getenv("RSX_ALLOC_MODE")) e->alloc_mode = std::max(0, std::min(2, std::atoi(env)));
-    if (const char* env = std::getenv("RSX_ALLOC_CHUNK_MB")) e->alloc_chunk = static_cast<size_t>(std::max(0, std::atoi(env))) << 20;
-    if (const char* env = std::getenv("RSX_XCD_REMAP")) e->xcd_remap = std::atoi(env) != 0;
-    if (const char* env = std::getenv("RSX_XCD_PHASE")) e->xcd_phase = std::atoll(env);
-    if (const char* env = std::getenv("RSX_REVERSE_ODD")) e->reverse_odd = std::atoi(env) != 0;
-    if (const char* env = std::getenv("RSX_LOOKAHEAD")) e->lookahead = std::atoi(env) != 0;
-    if (const char* env = std::getenv("RSX_GRAPH")) e->use_graph = std::atoi(env) != 0;
-    if (const char* env = std::getenv("RSX_SMALL_SCAN")) e->small_scan = std::atoi(env) != 0;
-    if (const char* env = std::getenv("RSX_TILE_SORT")) e->tile_sort = std::atoi(env) != 0;
-    if (const char* env = std::getenv("RSX_SELF_SCAN")) e->self_scan = std::atoi(env) != 0;
-    if (const char* env = std::getenv("RSX_SMALL_TILE_MAX_KEYS")) e->small_tile_max_keys = std::min<uint64_t>(std::strtoull(env, nullptr, 10), static_cast<uint64_t>(rsx::kSelfScanMaxTiles) * kTileThreads * kSmallKeysPerThread);
-    if (const char* env = std::getenv("RSX_SELF_SCAN_MAX")) e->self_scan_max = std::min<uint32_t>(static_cast<uint32_t>(std::atoi(env)), rsx::kSelfScanMaxTiles);
-    if (const char* env = std::getenv("RSX_RADIX_BITS")) e->radix_bits = std::atoi(env) == 8 ? 8 : 4;
-    if (const char* env = std::getenv("RSX_REORDER_EXTRA_LDS_KB")) e->reorder_extra_lds = std::atoi(env) < 0 ? -1L : static_cast<long>(std::min(64, std::atoi(env))) * 1024;
-    if (const char* env = std::getenv("RSX_R8_PACKED")) e->r8_packed = std::atoi(env) != 0;
-    if (const char* env = std::getenv("RSX_REORDER_WIDE")) e->reorder_wide = std::max(-1, std::min(1, std::atoi(env)));
-    if (const char* env = std::getenv("RSX_R8_WIDE")) e->r8_wide = std::max(-1, std::min(1, std::atoi(env)));
-    if (const char* env = std::getenv("RSX_R8_STAY")) e->r8_stay = std::max(-1, std::min(8, std::atoi(env)));
-    if (const char* env = std::getenv("RSX_R8_EXTRA_LDS_KB")) e->r8_extra_lds = std::atoi(env) < 0 ? -1L : static_cast<long>(std::min(96, std::atoi(env))) * 1024;
-    if (const char* env = std::getenv("RSX_REORDER8_V")) e->reorder8_version = std::max(1, std::min(3, std::atoi(env)));
-    if (const char* env = std::getenv("RSX_RADIX8_MIN_KEYS")) e->radix8_min_keys = std::max<uint64_t>(std::strtoull(env, nullptr, 10), kTileKeys);
-    if (const char* env = std::getenv("RSX_PASTE_SCAN")) e->paste_scan = std::atoi(env) != 0;
-    if (const char* env = std::getenv("RSX_FUSED_SCAN")) e->fused_scan = std::atoi(env) != 0;
-    if (const char* env = std::getenv("RSX_INLINE_SCAN")) e->inline_scan = std::atoi(env) != 0;
-    if (const char* env = std::getenv("RSX_INLINE_SCAN_MAX_GROUPS")) e->inline_scan_max_groups = static_cast<uint32_t>(std::max(0, std::atoi(env)));
-    if (const char* env = std::getenv("RSX_FOLD_PASTE")) e->fold_paste = std::atoi(env) != 0;
-    if (const char* env = std::getenv("RSX_SCAN_ZEROES")) e->scan_zeroes = std::atoi(env) != 0;
+    apply_environment(e);
 
     auto bail = [&](int status, const char* what, hipError_t err) {
         rsx_destroy(e);
@@ -1455,6 +1297,7 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
         return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(histograms)", err);
     if ((err = hipMalloc(reinterpret_cast<void**>(&e->counts_next), table_alloc)) != hipSuccess)
         return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(look-ahead counts)", err);
+#ifdef RSX_EXPERIMENTS
     {
         // the inline-scan chain serves tables of at most kFusedScanMaxGroups groups: its second count buffer need not be larger
         const size_t second = std::min<size_t>(table_alloc, static_cast<size_t>(rsx::kFusedScanMaxGroups) * rsx::kScanTiles * RSX_RADIX * 4);
@@ -1467,11 +1310,11 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
         if ((err = hipMemsetAsync(e->scan_ready, 0, rsx::kFusedScanMaxGroups * 4, e->stream)) != hipSuccess)
             return bail(RSX_INITIALIZATION_FAILED, "hipMemsetAsync(scan ready words)", err);
     }
+#endif
 #ifdef RSX_STAMPS
     if ((err = hipMalloc(reinterpret_cast<void**>(&e->stamps), e->ntiles(capacity) * 16 * 8)) != hipSuccess)
         return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(stamps)", err);
     if (const char* env = std::getenv("RSX_STAMP_PASS")) e->stamp_pass = std::atoi(env);
-    e->fold_paste = 0;
 #endif
     if ((err = hipMalloc(reinterpret_cast<void**>(&e->globsum), rsx::kMaxScanBlocks * 4)) != hipSuccess)
         return bail(RSX_INITIALIZATION_FAILED, "hipMalloc(globsum)", err);
@@ -1525,9 +1368,9 @@ int rsx_create(rsx_engine** out, int device, int key_bytes, int is_signed, int h
     if ((err = hipMemsetAsync(e->globsum, 0, rsx::kMaxScanBlocks * 4, e->stream)) != hipSuccess)
         return bail(RSX_INITIALIZATION_FAILED, "hipMemsetAsync(globsum)", err);
 
-    int rc = RSX_OK;
+    int rc = lds_base_probe(e);
 #if RSX_PRODUCT_SHAPE
-    {
+    if (rc == RSX_OK) {
         auto allow_tile = [](const void* fn, size_t bytes) { return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)); };
         using L32 = rsx::TileSortLayout<uint32_t, kTileThreads, kKeysPerThread>;
         using L64 = rsx::TileSortLayout<uint64_t, kTileThreads, kKeysPerThread>;
@@ -1583,8 +1426,11 @@ int rsx_destroy(rsx_engine* e)
     }
     if (e->table && hipFree(e->table) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->counts_next && hipFree(e->counts_next) != hipSuccess) status = RSX_CLEANUP_FAILED;
+#ifdef RSX_EXPERIMENTS
     if (e->counts_next2 && hipFree(e->counts_next2) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->scan_ready && hipFree(e->scan_ready) != hipSuccess) status = RSX_CLEANUP_FAILED;
+    if (e->tickets8 && hipFree(e->tickets8) != hipSuccess) status = RSX_CLEANUP_FAILED;
+#endif
     if (e->globsum && hipFree(e->globsum) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->globsum2 && hipFree(e->globsum2) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->temp && hipFree(e->temp) != hipSuccess) status = RSX_CLEANUP_FAILED;
@@ -1593,7 +1439,6 @@ int rsx_destroy(rsx_engine* e)
         if (e->cnt3[i] && hipFree(e->cnt3[i]) != hipSuccess) status = RSX_CLEANUP_FAILED;
     }
     if (e->counts8 && hipFree(e->counts8) != hipSuccess) status = RSX_CLEANUP_FAILED;
-    if (e->tickets8 && hipFree(e->tickets8) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->table8 && hipFree(e->table8) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->gsum8 && hipFree(e->gsum8) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->csum8 && hipFree(e->csum8) != hipSuccess) status = RSX_CLEANUP_FAILED;
@@ -1601,6 +1446,11 @@ int rsx_destroy(rsx_engine* e)
     if (e->scan_timeout_host && hipHostFree(e->scan_timeout_host) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->starts_dev && hipFree(e->starts_dev) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->peer_dev && hipFree(e->peer_dev) != hipSuccess) status = RSX_CLEANUP_FAILED;
+    if (e->msd_plan && hipFree(e->msd_plan) != hipSuccess) status = RSX_CLEANUP_FAILED;
+    if (e->msd_starts && hipFree(e->msd_starts) != hipSuccess) status = RSX_CLEANUP_FAILED;
+    if (e->msd_plan_host && hipHostFree(e->msd_plan_host) != hipSuccess) status = RSX_CLEANUP_FAILED;
+    if (e->msd_event) (void)hipEventDestroy(e->msd_event);
+    if (e->order_event) (void)hipEventDestroy(e->order_event);
     if (e->range_dev && hipFree(e->range_dev) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->ref_table && hipFree(e->ref_table) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->ref_globsum && hipFree(e->ref_globsum) != hipSuccess) status = RSX_CLEANUP_FAILED;
@@ -1660,30 +1510,38 @@ int rsx_set_option(rsx_engine* e, int option, int64_t value)
     case RSX_OPT_SMALL_SCAN: e->small_scan = value != 0; return RSX_OK;
     case RSX_OPT_TILE_SORT: e->tile_sort = value != 0; return RSX_OK;
     case RSX_OPT_FUSED_SCAN: e->fused_scan = value != 0; return RSX_OK;
-    case RSX_OPT_REORDER8_KERNEL:
+#ifdef RSX_EXPERIMENTS
+    case RSX_XOPT_REORDER8_KERNEL:
         if (value < 1 || value > 3) return fail(RSX_CALCULATION_FAILED, "rsx_set_option: the 8-bit scatter kernel is 1, 2 or 3");
         e->reorder8_version = static_cast<int>(value);
         return RSX_OK;
-    case RSX_OPT_REORDER8_STAY:
-        if (value < -1 || value > 8) return fail(RSX_CALCULATION_FAILED, "rsx_set_option: workgroups per CU of the staying 8-bit scatter: -1 (policy), 0 (off) .. 8");
+    case RSX_XOPT_REORDER8_STAY:
+        if (value < -1 || value > 8) return fail(RSX_CALCULATION_FAILED, "rsx_set_option: workgroups per CU of the staying 8-bit scatter: -1 / 0 (off) .. 8");
         e->r8_stay = static_cast<int>(value);
         return RSX_OK;
-    case RSX_OPT_INLINE_SCAN: e->inline_scan = value != 0; return RSX_OK;
-    case RSX_OPT_INLINE_SCAN_MAX_GROUPS:
+    case RSX_XOPT_INLINE_SCAN:
+        e->inline_scan = value != 0;
+        if (e->inline_scan && e->inline_scan_limit == 0) {
+            if (bind_device(e, RSX_INITIALIZATION_FAILED) != RSX_OK) return RSX_INITIALIZATION_FAILED;
+            return RSX_BY_KEY(e, inline_scan_prepare<uint32_t>(e), inline_scan_prepare<uint64_t>(e));
+        }
+        return RSX_OK;
+    case RSX_XOPT_INLINE_SCAN_MAX_GROUPS:
         if (value < 0) return fail(RSX_CALCULATION_FAILED, "rsx_set_option: negative group count");
         e->inline_scan_max_groups = static_cast<uint32_t>(std::min<int64_t>(value, rsx::kFusedScanMaxGroups));
         return RSX_OK;
+    case RSX_XOPT_DEBUG_RAISE_SCAN_TIMEOUT:
+        // tests only: stores to the time-out word exactly as a fused-scan workgroup whose poll ran out does
+        if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
+        hipLaunchKernelGGL(rsx::raise_flag_kernel, dim3(1), dim3(64), 0, e->stream, e->scan_timeout);
+        RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
+        return RSX_OK;
+#endif
     case RSX_OPT_FUSED_SCAN_MAX_GROUPS:
         // never beyond what the occupancy query says is resident at once (nor the granule buffer): -1 restores the default
         if (value < -1) return fail(RSX_CALCULATION_FAILED, "rsx_set_option: negative group count");
         e->fused_scan_limit = value < 0 ? std::min<uint32_t>(e->fused_scan_resident / 2, rsx::kFusedScanMaxGroups)
                                         : static_cast<uint32_t>(std::min<int64_t>(value, std::min<uint32_t>(e->fused_scan_resident, rsx::kFusedScanMaxGroups)));
-        return RSX_OK;
-    case RSX_OPT_DEBUG_RAISE_SCAN_TIMEOUT:
-        // tests only: stores to the time-out word exactly as a fused-scan workgroup whose poll ran out does
-        if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
-        hipLaunchKernelGGL(rsx::raise_flag_kernel, dim3(1), dim3(64), 0, e->stream, e->scan_timeout);
-        RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
         return RSX_OK;
     case RSX_OPT_SELF_SCAN: e->self_scan = value != 0; return RSX_OK;
     case RSX_OPT_SMALL_TILE_MAX_KEYS:
@@ -2231,11 +2089,11 @@ int rsx_partition_scatter_split(rsx_engine* e, const void* d_keys, const uint32_
     const uint32_t* pin = with_payload ? d_payload : nullptr;
     uint32_t* pout = with_payload ? d_payload_out : nullptr;
     if (e->key_bytes == 4) {
-        return with_payload ? launch_reorder_t<uint32_t, true, false, true>(e, d_keys, d_keys_out, pin, pout, n, 0, RSX_RADIX - 1, 0, false, 0u, 0u, e->nsplit)
-                            : launch_reorder_t<uint32_t, false, false, true>(e, d_keys, d_keys_out, nullptr, nullptr, n, 0, RSX_RADIX - 1, 0, false, 0u, 0u, e->nsplit);
+        return with_payload ? launch_reorder_t<uint32_t, true, false, true>(e, d_keys, d_keys_out, pin, pout, n, 0, RSX_RADIX - 1, 0, 0u, 0u, e->nsplit)
+                            : launch_reorder_t<uint32_t, false, false, true>(e, d_keys, d_keys_out, nullptr, nullptr, n, 0, RSX_RADIX - 1, 0, 0u, 0u, e->nsplit);
     }
-    return with_payload ? launch_reorder_t<uint64_t, true, false, true>(e, d_keys, d_keys_out, pin, pout, n, 0, RSX_RADIX - 1, 0, false, 0ull, 0ull, e->nsplit)
-                        : launch_reorder_t<uint64_t, false, false, true>(e, d_keys, d_keys_out, nullptr, nullptr, n, 0, RSX_RADIX - 1, 0, false, 0ull, 0ull, e->nsplit);
+    return with_payload ? launch_reorder_t<uint64_t, true, false, true>(e, d_keys, d_keys_out, pin, pout, n, 0, RSX_RADIX - 1, 0, 0ull, 0ull, e->nsplit)
+                        : launch_reorder_t<uint64_t, false, false, true>(e, d_keys, d_keys_out, nullptr, nullptr, n, 0, RSX_RADIX - 1, 0, 0ull, 0ull, e->nsplit);
 }
 
 namespace {
@@ -2330,11 +2188,11 @@ int scatter_waves(rsx_engine* e, const char* who, const void* d_keys, const uint
     e->wave_rot = static_cast<uint32_t>(e->counted_bits % RSX_RADIX_BITS);
     const rsx::SelfScanArgs none{nullptr, nullptr, nullptr};
     if (e->key_bytes == 4) {
-        rc = with_payload ? launch_reorder_t<uint32_t, true, false, true>(e, d_keys, d_keys_out, pin, pout, n, shift, RSX_RADIX - 1, 0, false, 0u, 0u, 0, none, nullptr, peer)
-                          : launch_reorder_t<uint32_t, false, false, true>(e, d_keys, d_keys_out, nullptr, nullptr, n, shift, RSX_RADIX - 1, 0, false, 0u, 0u, 0, none, nullptr, peer);
+        rc = with_payload ? launch_reorder_t<uint32_t, true, false, true>(e, d_keys, d_keys_out, pin, pout, n, shift, RSX_RADIX - 1, 0, 0u, 0u, 0, none, nullptr, peer)
+                          : launch_reorder_t<uint32_t, false, false, true>(e, d_keys, d_keys_out, nullptr, nullptr, n, shift, RSX_RADIX - 1, 0, 0u, 0u, 0, none, nullptr, peer);
     } else {
-        rc = with_payload ? launch_reorder_t<uint64_t, true, false, true>(e, d_keys, d_keys_out, pin, pout, n, shift, RSX_RADIX - 1, 0, false, 0ull, 0ull, 0, none, nullptr, peer)
-                          : launch_reorder_t<uint64_t, false, false, true>(e, d_keys, d_keys_out, nullptr, nullptr, n, shift, RSX_RADIX - 1, 0, false, 0ull, 0ull, 0, none, nullptr, peer);
+        rc = with_payload ? launch_reorder_t<uint64_t, true, false, true>(e, d_keys, d_keys_out, pin, pout, n, shift, RSX_RADIX - 1, 0, 0ull, 0ull, 0, none, nullptr, peer)
+                          : launch_reorder_t<uint64_t, false, false, true>(e, d_keys, d_keys_out, nullptr, nullptr, n, shift, RSX_RADIX - 1, 0, 0ull, 0ull, 0, none, nullptr, peer);
     }
     e->wave_rot = 0;
     return rc;
@@ -2442,6 +2300,8 @@ int rsx_peer_enable(rsx_engine* e, int peer_device)
     (void)hipGetLastError();
     return RSX_OK;
 }
+
+#include "capi_msd.inc"
 
 int rsx_key_range(rsx_engine* e, const void* d_keys, uint64_t n, uint64_t* lo, uint64_t* hi)
 {

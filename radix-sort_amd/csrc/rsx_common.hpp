@@ -27,22 +27,10 @@ struct alignas(16) U32x4 {
     uint32_t v[4];
 };
 
-// Keys are read exactly once per pass: RSX_STREAM_LOADS=1 marks those 16-byte loads non-temporal (experiment, tuning log §7).
-#ifndef RSX_STREAM_LOADS
-#define RSX_STREAM_LOADS 0
-#endif
 template <typename Key>
 __device__ __forceinline__ KeyVec<Key> load_keys16(const Key* p)
 {
-#if RSX_STREAM_LOADS
-    typedef uint32_t u32x4_native __attribute__((ext_vector_type(4)));
-    const u32x4_native x = __builtin_nontemporal_load(reinterpret_cast<const u32x4_native*>(p));
-    KeyVec<Key> v;
-    __builtin_memcpy(&v, &x, 16);
-    return v;
-#else
     return *reinterpret_cast<const KeyVec<Key>*>(p);
-#endif
 }
 
 // The packed counters in LDS are touched as 16-bit halves, 32-bit words and 16-byte

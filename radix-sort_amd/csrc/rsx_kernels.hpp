@@ -36,6 +36,7 @@
 //   rsx_tile_sort.hpp  tile_sort_kernel
 //   rsx_radix8.hpp     histogram8 / scan8_* / reorder8
 //   rsx_util.hpp       reference-geometry diagnostics and the small helpers of the multi-GPU partition
+//   rsx_msd.hpp        the sharded sort's exchange step on the top B <= 8 bits: wave-major bucket starts, device-side plan, per-wave push
 #pragma once
 
 #include "rsx_common.hpp"
@@ -45,3 +46,7 @@
 #include "rsx_tile_sort.hpp"
 #include "rsx_radix8.hpp"
 #include "rsx_util.hpp"
+#include "rsx_msd.hpp"
+#ifdef RSX_EXPERIMENTS
+#include "rsx_radix8_experiments.hpp"      // rejected alternatives, A/B builds only
+#endif

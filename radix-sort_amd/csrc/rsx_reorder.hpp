@@ -36,36 +36,13 @@ struct alignas(8) RunBase {
 // wave targets ONE counter (constant or sorted data: every pass of Zeros, most passes of
 // Range) the uniform branch lets lane 0 add 64 instead of 64 lanes serialising on one address.
 constexpr uint32_t kLaDummy = 2 * kRadix * kRadix;   // one spare counter past the 512 real ones
-// RSX_LA_REPLICAS=2 (default): every counter in two adjacent copies, odd and even lanes adding to different ones, so that the 32
+// Two replicas: every counter in two adjacent copies, odd and even lanes adding to different ones, so that the 32
 // lanes of one LDS pass hit 32 different words instead of piling two deep on 16 addresses.  Before the XCD stagger this made no
 // difference (the kernel waited for HBM); with it, interleaved A/B: 3.345-3.392 against 3.369-3.423 ms per sort back to back,
 // and 0.417-0.424 against 0.430-0.447 ms per scatter launch right after an upload, when the shader clock is low and the waves
 // wait for LDS issue (SQ counters: 23 % of their cycles, bank conflicts on 49 % of the LDS cycles with one copy).
-#ifndef RSX_EARLY_RANK
-#define RSX_EARLY_RANK 1
-#endif
-// RSX_STREAM_STORES=1 (experiment, tuning log r03 §6): the scatter's key / payload stores carry the non-temporal hint — the output of a
-// pass is read again only after the whole pass, long after it has left every cache.
-#ifndef RSX_STREAM_STORES
-#define RSX_STREAM_STORES 0
-#endif
-template <typename T>
-__device__ __forceinline__ void scatter_store(T* p, T v)
-{
-#if RSX_STREAM_STORES
-    __builtin_nontemporal_store(v, p);
-#else
-    *p = v;
-#endif
-}
-#ifndef RSX_SCAN_TRAILING_BARRIER
-#define RSX_SCAN_TRAILING_BARRIER 0      // round 3: the raking scan's block scan ends without its own barrier (one barrier fewer per tile)
-#endif
-#ifndef RSX_LA_REPLICAS
-#define RSX_LA_REPLICAS 2
-#endif
-constexpr int kLaReplicas = RSX_LA_REPLICAS;
-static_assert(kLaReplicas == 1 || kLaReplicas == 2, "odd/even-lane replicas");
+// (non-temporal key loads / scatter stores were measured and rejected: profiles/r03_tuning_log.md §6-7)
+constexpr int kLaReplicas = 2;
 
 // (the payload kernels keep one copy: their A/B showed nothing beyond run-to-run noise, and they are the ones short of registers;
 // so do the 64-bit keys-only kernels: 13.03 against 13.15 ms per 2^28-key sort with one copy)
@@ -100,15 +77,12 @@ __device__ __forceinline__ uint32_t add_lshl(uint32_t a, uint32_t b)
 // A store to the workgroup's LDS at a BYTE OFFSET from its start.  The kernels below carve everything out of one
 // `extern __shared__` array and declare no static LDS, so that array starts at LDS address 0 — but hipcc
 // only learns this after instruction selection and otherwise spends one `v_add_u32 addr, 0, addr` per
-// computed address.  reorder_kernel checks the assumption once per workgroup (lds_base_is_zero).
+// computed address.  The assumption is checked on the host, once per engine: every kernel that uses this is asked for its static LDS size
+// (must be 0) and a probe kernel reports where a lone dynamic array starts (rsx_create -> RSX_KERNEL_CREATION_FAILED otherwise).
 template <typename T>
 __device__ __forceinline__ void lds_store_at(uint32_t byte_offset, T value)
 {
     *reinterpret_cast<__attribute__((address_space(3))) T*>(static_cast<uintptr_t>(byte_offset)) = value;
-}
-__device__ __forceinline__ bool lds_base_is_zero(const void* dynamic_lds)
-{
-    return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) const char*)dynamic_lds)) == 0u;
 }
 
 // The 32-bit word of a key that holds the bit field starting at `shift` (fields never straddle the two
@@ -132,16 +106,9 @@ __device__ __forceinline__ uint32_t field_word(uint64_t key, bool hi) { return h
 #define RSX_STAMP(k) do { } while (0)
 #endif
 
-// ALIAS (optional, -DRSX_ALIAS_COUNTERS=1): the packed counters share LDS with the staging image (they are dead once every thread
-// has read its 16 "first slot of my digit" values, which is when the image starts to fill; one extra barrier in between).  That
-// takes a uint32 tile from 28 to 20 KiB and a uint64 tile from 46 to 37 KiB: 6 instead of 5, and 4 instead of 3, resident
-// workgroups per CU.  Measured with six interleaved runs per build (the runs are bimodal, 2-3 % apart, so pairs mislead):
-// uint32 3.67 / 3.76 ms against 3.62 / 3.71 without, uint64 13.15-13.43 against 12.92-13.34, uint64+payload 18.04-18.20 against
-// 18.19-18.29 — the barrier costs more than the occupancy gives.  Off.
-#ifndef RSX_ALIAS_COUNTERS
-#define RSX_ALIAS_COUNTERS 0
-#endif
-template <typename Key, int THREADS, int KPT, bool ALIAS = (RSX_ALIAS_COUNTERS != 0)>
+// (the packed counters sharing LDS with the staging image — one workgroup more per CU for one barrier more per tile — was measured
+// and rejected: profiles/r01_tuning_log.md)
+template <typename Key, int THREADS, int KPT>
 struct ReorderLayout {
     static constexpr int TILE = THREADS * KPT;
     static constexpr int KD = sizeof(Key) / 4;
@@ -149,8 +116,8 @@ struct ReorderLayout {
     static constexpr int XELEMS = TILE + (TILE >> PADSH);
     static constexpr int XBUF_DW = XELEMS * KD;
     static constexpr int CNT_DW = 8 * THREADS;
-    static constexpr int CNT_AT = ALIAS ? 0 : XBUF_DW;                              // dword offset of the counters
-    static constexpr int IMAGE_DW = ALIAS ? (XBUF_DW > CNT_DW ? XBUF_DW : CNT_DW) : XBUF_DW + CNT_DW;
+    static constexpr int CNT_AT = XBUF_DW;                                          // dword offset of the counters
+    static constexpr int IMAGE_DW = XBUF_DW + CNT_DW;
     static constexpr int WTOT_DW = 16;
     static constexpr int GBASE_DW = 2 * kRadix;             // per digit {gbase, la_base}: one ds_read_b64
     static constexpr int LA_DW = kLaReplicas * (kRadix * 2 * kRadix + 8);  // look-ahead counters [digit][segment 0/1][next digit][replica] + dummies
@@ -164,10 +131,8 @@ struct ReorderLayout {
     // __launch_bounds__ argument = waves per SIMD, not blocks per CU); never asked beyond 6 (80 VGPRs: what the keys-only
     // kernels need; 8 would mean 64 and spills).
     static constexpr int WGS_PER_CU = static_cast<int>((160 * 1024) / BYTES);
-#ifndef RSX_REORDER_WAVES_CAP
-#define RSX_REORDER_WAVES_CAP 6      // 7 (72 VGPRs) measured twice, before and after the XCD stagger: see the tuning log
-#endif
-    static constexpr int MIN_WAVES = (WGS_PER_CU * THREADS / 256) > RSX_REORDER_WAVES_CAP ? RSX_REORDER_WAVES_CAP : (WGS_PER_CU * THREADS / 256);
+    static constexpr int WAVES_CAP = 6;      // 7 (72 VGPRs) measured twice, before and after the XCD stagger: see the tuning log
+    static constexpr int MIN_WAVES = (WGS_PER_CU * THREADS / 256) > WAVES_CAP ? WAVES_CAP : (WGS_PER_CU * THREADS / 256);
     static_assert(TILE <= 32768, "16-bit packed counters");
     static_assert(KPT % (16 / sizeof(Key)) == 0 && THREADS % 64 == 0 && THREADS % 8 == 0, "geometry");
 };
@@ -177,7 +142,7 @@ struct ReorderLayout {
 template <typename Key, int THREADS, int KPT, bool PAYLOAD, bool RANGED = false>
 constexpr int reorder_min_waves()
 {
-    constexpr int w = ReorderLayout<Key, THREADS, KPT, (!RANGED && RSX_ALIAS_COUNTERS != 0)>::MIN_WAVES;
+    constexpr int w = ReorderLayout<Key, THREADS, KPT>::MIN_WAVES;
     constexpr int cap = 4 * THREADS / 256;
     return (PAYLOAD && w > cap) ? cap : w;
 }
@@ -231,8 +196,10 @@ struct InlineScanArgs {
 // (mask 15) and the next digit the field at `next_shift`.  It works on RAW fields (no sign flip per
 // key): the sign bit only ever toggles the top bit of the top digit, which is folded into where the
 // counters, the run bases and the flushed counts are PLACED (flip_cur / flip_next below).
+// INLINE_SCAN kernels are instantiated by the experiments build only (-DRSX_EXPERIMENTS: measured slower than the scan launch they remove); the fused-scan
+// body they carry needs registers of its own (142 VGPRs): three waves per SIMD are asked of them, otherwise the uint32 variants spill (52-180 bytes per lane in round 3).
 template <typename Key, int THREADS, int KPT, bool PAYLOAD, bool LOOKAHEAD, bool RANGED = false, bool INLINE_SCAN = false>
-__global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYLOAD, RANGED>())) void reorder_kernel(const Key* __restrict__ in, Key* __restrict__ out,
+__global__ __launch_bounds__(THREADS, (INLINE_SCAN ? 3 : reorder_min_waves<Key, THREADS, KPT, PAYLOAD, RANGED>())) void reorder_kernel(const Key* __restrict__ in, Key* __restrict__ out,
                                                            const uint32_t* __restrict__ pin, uint32_t* __restrict__ pout,
                                                            const uint32_t* table, uint64_t n, uint32_t ntiles,
                                                            uint32_t tiles_per_xcd, int remap, int shift, Key flip, uint32_t mask,
@@ -242,7 +209,7 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
                                                            InlineScanArgs iscan = InlineScanArgs{})
 {
     static_assert(!INLINE_SCAN || (!RANGED && THREADS == kScanTiles), "the inline scan is the fused scan's workgroup: 256 threads, rsx_sort's passes only");
-    using L = ReorderLayout<Key, THREADS, KPT, (!RANGED && RSX_ALIAS_COUNTERS != 0)>;
+    using L = ReorderLayout<Key, THREADS, KPT>;
     static_assert(!(RANGED && LOOKAHEAD), "the ranged bucket function is for the one-pass partition only");
     constexpr bool RAW = LOOKAHEAD;                 // digits are raw 4-bit fields; the sign flip lives in the placement
     constexpr int TILE = L::TILE;
@@ -268,13 +235,12 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
             __syncthreads();                        // the scratch is this workgroup's dynamic LDS again
         }
     }
-    const uint32_t slot_tile = tile_of_block(blockIdx.x, tiles_per_xcd, remap & ~2);
-    if (slot_tile >= ntiles) {
+    const uint32_t tile = tile_of_block(blockIdx.x, tiles_per_xcd, remap);
+    if (tile >= ntiles) {
         return;
     }
-    if (!lds_base_is_zero(smem)) {
-        __builtin_trap();           // lds_store_at addresses the staging image from LDS address 0
-    }
+    // (lds_store_at addresses the staging image from LDS address 0: rsx_create checks once, on the host, that this kernel has no static
+    // LDS in front of its dynamic array and that such an array starts at 0 on this device — KERNEL_CREATION_FAILED otherwise)
     // peer-store launches: the 16 destination addresses (self-scan scratch, unused in RANGED launches; read after several barriers)
     const bool to_peers = RANGED && peer.keys != nullptr;                 // wave-uniform
     unsigned long long* peer_k = reinterpret_cast<unsigned long long*>(self_part);
@@ -290,8 +256,6 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
             }
         }
     }
-    // bit 1 of `remap`: walk the tiles from the back (experiment: start with what the previous pass wrote last)
-    const uint32_t tile = (remap & 2) ? ntiles - 1 - slot_tile : slot_tile;
     const uint64_t base = static_cast<uint64_t>(tile) * TILE;
     const uint64_t left = n - base;
     const uint32_t valid = left < static_cast<uint64_t>(TILE) ? static_cast<uint32_t>(left) : static_cast<uint32_t>(TILE);
@@ -345,10 +309,7 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
     // (the pieces of the two table entries stay apart until phase 3 adds them up: summed here, inside the raking threads' branch, the adds and with them
     // the wait for these loads would stand BEFORE the key loads of the wave)
     uint32_t first_lo = 0, first_hi = 0, group_lo = 0, group_hi = 0, bucket_lo = 0, bucket_hi = 0;
-#ifndef RSX_SELF_SCAN_KERNEL
-#define RSX_SELF_SCAN_KERNEL 1
-#endif
-    const bool self_scan = RSX_SELF_SCAN_KERNEL && !RANGED && self.counts != nullptr;      // wave-uniform
+    const bool self_scan = !RANGED && self.counts != nullptr;      // wave-uniform
     if (rake_head && !self_scan && !INLINE_SCAN) {
         const uint64_t e_lo = static_cast<uint64_t>(hl) * ntiles + tile;
         const uint64_t e_hi = static_cast<uint64_t>(hl + 8) * ntiles + tile;
@@ -539,9 +500,7 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
         for (int i = 0; i < KPT; ++i) {
             const uint32_t sh4 = bucket_at(i) << 2;
             slot[i] = static_cast<uint32_t>(seen >> sh4) & 15u;
-#if RSX_EARLY_RANK
             asm volatile("" : "+v"(slot[i]));      // materialise the rank now: otherwise hipcc keeps all 16 intermediate `seen` values (32 VGPRs) and extracts the ranks after the loop
-#endif
             if (i + 1 < KPT) {
                 seen += 1ull << sh4;
             }
@@ -604,7 +563,7 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
         const uint32_t sum = a.v[0] + a.v[1] + a.v[2] + a.v[3] + b.v[0] + b.v[1] + b.v[2] + b.v[3];
         uint32_t total;
         // (no trailing barrier: `wtot` is not written again in this kernel, and the barrier after the packed words below orders the rest)
-        uint32_t run = block_exclusive_scan<THREADS, (RSX_SCAN_TRAILING_BARRIER != 0)>(sum, wtot, total);
+        uint32_t run = block_exclusive_scan<THREADS, false>(sum, wtot, total);
         // low halves now prefix digits 0..7, high halves digits 8..15; the latter start
         // after ALL keys with digit < 8, i.e. after total.low
         run += total << 16;
@@ -647,9 +606,6 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
             slot[i] += first_of_digit[i];
-        }
-        if constexpr (L::CNT_AT == 0) {
-            __syncthreads();                 // the image overlays the counters: nobody may still be reading them
         }
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
@@ -717,7 +673,7 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
     } else if (full) {
 #pragma unroll
         for (int r = 0; r < KPT; ++r) {
-            scatter_store(&out[g[r]], okey[r]);
+            out[g[r]] = okey[r];
         }
     } else {
 #pragma unroll
@@ -775,7 +731,7 @@ __global__ __launch_bounds__(THREADS, (reorder_min_waves<Key, THREADS, KPT, PAYL
                         continue;
                     }
                 }
-                scatter_store(&pout[g[r]], pay[r]);
+                pout[g[r]] = pay[r];
             }
         }
     }

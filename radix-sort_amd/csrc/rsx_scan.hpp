@@ -397,13 +397,15 @@ __global__ __launch_bounds__(kScanTiles) void scan_fused_kernel(uint32_t* __rest
     fused_scan_group<ZERO_BACK, false>(lds, blockIdx.x, table, sums, scanned, temp, ntiles, ngroups, counts, FROM_COUNTS, epoch, timeout, nullptr);
 }
 
-// tests only (RSX_OPT_DEBUG_RAISE_SCAN_TIMEOUT): the store a timed-out sweep makes, without the sweep
+#ifdef RSX_EXPERIMENTS
+// tests only (RSX_XOPT_DEBUG_RAISE_SCAN_TIMEOUT, experiments build): the store a timed-out sweep makes, without the sweep
 __global__ void raise_flag_kernel(uint32_t* flag)
 {
     if (threadIdx.x == 0) {
         __hip_atomic_store((gu32*)(flag), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
+#endif
 
 // Whole table scan in ONE workgroup — scan #1, scan #2 and paste of a small table in a single
 // launch.  Up to 2^22 keys a pass is so short that the three tiny kernels above and their launch

@@ -146,6 +146,16 @@ __global__ void fill_kernel(Key* __restrict__ dst, uint64_t first, uint64_t coun
     }
 }
 
+// where does a kernel's lone dynamic LDS array start?  (rsx_create: the scatter kernels address their image from LDS address 0)
+__global__ void lds_base_probe_kernel(uint32_t* out)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t probe_smem[];
+    if (threadIdx.x == 0) {
+        probe_smem[0] = 1;
+        out[0] = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) const char*)probe_smem));
+    }
+}
+
 // per-digit totals of a RAW counter table: out[d] = sum over tiles of table[d][tile] (one workgroup per digit)
 __global__ __launch_bounds__(256) void digit_totals_kernel(const uint32_t* __restrict__ table, uint32_t ntiles, unsigned long long* __restrict__ out)
 {

@@ -46,10 +46,17 @@ def test_option_constants_match_the_header(rsx):
     """every RSX_OPT_* of include/radixsort_hip.h has its OPT_* twin in the binding with the same value, and no value is used twice"""
     text = open(HEADER).read()
     opts = {n: int(v) for n, v in re.findall(r"RSX_OPT_([A-Z0-9_]+)\s*=\s*(\d+)", text)}
-    assert len(opts) >= 21 and len(set(opts.values())) == len(opts)
+    assert len(opts) >= 16 and len(set(opts.values())) == len(opts)
     for name, value in opts.items():
         assert getattr(rsx, "OPT_" + name) == value, name
     assert {n[4:] for n in dir(rsx) if n.startswith("OPT_")} == set(opts)
+    # the experiments build's options live in a header of their own, beside values the product does not use
+    xtext = open(os.path.join(ROOT, "include", "radixsort_hip_experiments.h")).read()
+    xopts = {n: int(v) for n, v in re.findall(r"RSX_XOPT_([A-Z0-9_]+)\s*=\s*(\d+)", xtext)}
+    assert len(xopts) == 5 and not set(xopts.values()) & set(opts.values())
+    for name, value in xopts.items():
+        assert getattr(rsx, "XOPT_" + name) == value, name
+    assert "RSX_XOPT" not in text and "DEBUG_RAISE" not in text          # no test hook in the public enum
 
 
 def test_library_is_gfx950_code_object(rsx):

@@ -9,7 +9,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as entry
 
-m = entry.load_package()
+EXPERIMENTS = os.environ.get("SOAK_EXPERIMENTS") == "1"
+m = entry.load_package().experiments() if EXPERIMENTS else entry.load_package()
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
 cap = int(os.environ.get("RSX_SOAK_CAP", 9_000_000))      # 2,197 tiles: both sides of the self-scan / fused-scan border
@@ -42,12 +43,12 @@ for it in range(iters):
     e.set_option(m.OPT_XCD_PHASE, (-1, 0, int(rng.integers(1, 40)))[rng.integers(0, 3)])
     e.set_option(m.OPT_SMALL_TILE_MAX_KEYS, (1 << 19, 0, 1 << 20)[rng.integers(0, 3)])
     e.set_option(m.OPT_SELF_SCAN_MAX_TILES, (1024, 1024, 100)[rng.integers(0, 3)])
-    # round 3: the scan inside the reorder launch, the fused scan's group limit, the three 8-bit scatter kernels
-    e.set_option(m.OPT_INLINE_SCAN, int(rng.integers(0, 2)))
-    e.set_option(m.OPT_INLINE_SCAN_MAX_GROUPS, (64, 2, 512)[rng.integers(0, 3)])
     e.set_option(m.OPT_FUSED_SCAN_MAX_GROUPS, (-1, 1, 0)[rng.integers(0, 3)])
-    e.set_option(m.OPT_REORDER8_KERNEL, int(rng.integers(1, 4)))
-    e.set_option(m.OPT_REORDER8_STAY, (0, 0, 1, 2)[rng.integers(0, 4)])
+    if EXPERIMENTS:      # SOAK_EXPERIMENTS=1: the experiments build — the scan inside the reorder launch, the three 8-bit scatter kernels, the staying grid
+        e.set_option(m.XOPT_INLINE_SCAN, int(rng.integers(0, 2)))
+        e.set_option(m.XOPT_INLINE_SCAN_MAX_GROUPS, (64, 2, 512)[rng.integers(0, 3)])
+        e.set_option(m.XOPT_REORDER8_KERNEL, int(rng.integers(1, 4)))
+        e.set_option(m.XOPT_REORDER8_STAY, (0, 0, 1, 2)[rng.integers(0, 4)])
     perm = np.arange(n, dtype=np.uint32) if payload else None
     e.upload(keys, perm)
     e.sort()
