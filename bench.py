@@ -105,14 +105,34 @@ def cpu_baseline(sample: np.ndarray, whole: bool):
     return entry, ordered
 
 
+def kernel_source_digest() -> str:
+    """sha256[:16] over the kernel sources (radix-sort_amd/csrc, sorted by name) — the same function as tools/pmc_summarize.py, which
+    stamps every PMC summary with it."""
+    import hashlib
+    csrc = os.path.join(ROOT, "radix-sort_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".hpp", ".inc")):
+            h.update(name.encode() + b"\0" + open(os.path.join(csrc, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def load_traffic(workload: str):
-    """HBM bytes per reorder launch from rocprofv3 PMC passes, if a summary was committed."""
+    """(HBM bytes per reorder launch from the committed rocprofv3 PMC passes, note).  The figure is a replay of profiles/pmc_traffic.json,
+    not a counter read in this run (PMC collection needs rocprofv3 around the process), so it is printed only while the kernel sources
+    still hash to what the passes were taken on; otherwise traffic is null and the note says why."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(workload, {}).get("reorder_hbm_bytes_per_launch")
+            entry = json.load(f).get(workload)
     except (OSError, ValueError):
-        return None
+        entry = None
+    if not entry:
+        return None, "no PMC pass committed for this workload"
+    now = kernel_source_digest()
+    if entry.get("kernel_source_digest") != now:
+        return None, f"the committed PMC pass was taken on other kernel sources ({entry.get('kernel_source_digest', 'unstamped')} != {now}): re-run tools/final_profiles.sh"
+    return entry.get("reorder_hbm_bytes_per_launch"), f"replayed from profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on kernel sources {now})"
 
 
 def free_port() -> int:
@@ -161,6 +181,8 @@ def parse_args(argv=None):
     ap.add_argument("--dataset", default="Random", choices=list(KIND_CODES))
     ap.add_argument("--cpu-sample-log2", type=int, default=None, help="CPU baseline sample = first 2^this keys of rank 0's input (default: 28 at N=1 = the whole workload, ~13 s; 26 at N>1)")
     ap.add_argument("--radix-bits", type=int, default=4, choices=[4, 8], help="digit width: 4 = the reference's configuration and the headline; 8 = half the passes, reported as a separate row")
+    ap.add_argument("--partition-bits", type=int, default=int(os.environ.get("RSX_PARTITION_BITS", "0")) or None,
+                    help="N>1: top key bits of the exchange partition = pipeline depth, 2^bits / N waves per rank (default: 8 waves per rank, at least 4 bits)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-verify-full", action="store_true", help="N>1: skip the gather of all outputs on rank 0 and keep only the checksum / boundary checks")
@@ -258,7 +280,10 @@ def main() -> None:
     eng.set_option(rsx.OPT_PROFILE, 0 if args.no_events else 2)
     if args.radix_bits != 4:
         eng.set_option(rsx.OPT_RADIX_BITS, args.radix_bits)
-    sorter = ShardedSorter(eng, rank, world, key_bytes * 8, dist, force_exchange=force_exchange, strategy=os.environ.get("RSX_STRATEGY", "auto"))
+    sorter = ShardedSorter(eng, rank, world, key_bytes * 8, dist, force_exchange=force_exchange, strategy=os.environ.get("RSX_STRATEGY", "auto"),
+                           partition_bits=args.partition_bits)
+    if os.environ.get("RSX_PUSH_PARTS"):
+        sorter.push_parts = int(os.environ["RSX_PUSH_PARTS"])
     if sharded and sorter.strategy == "waves-p2p":
         # peer-store exchange: the receive buffers are peer-visible device memory that the other ranks' scatter kernels write into
         sorter.setup_peer_exchange(capacity, device, args.payload)
@@ -392,8 +417,11 @@ def main() -> None:
     # N>1: launches differ in size (the partition pass sees n keys, the local passes what arrived,
     # wave by wave on the pipelined path), so the figure is bytes of all launches / time of all launches
     passes = key_bytes * 8 // args.radix_bits
+    waves = sorter.last_path in ("waves", "waves-p2p")
     if sharded:
-        local_passes = passes - 1 if sorter.last_path in ("waves", "waves-p2p") else passes
+        from radix_sort_amd.distributed import local_pass_units
+        units = local_pass_units(key_bytes * 8, sorter.partition_bits) if waves else key_bytes * 2      # 4-bit pass units of a local sort
+        local_passes = units if args.radix_bits == 4 else units // 2 + units % 2                          # ... = scatter launches (8-bit: whole bytes + a nibble)
         scatter_bytes_per_step = 2.0 * (key_bytes + pay_bytes) * (n + local_passes * n_local)
         scatter_bytes = scatter_bytes_per_step / launches_per_step if launches_per_step else 0.0
     else:
@@ -408,6 +436,7 @@ def main() -> None:
         workload = f"{pow2(total_keys)} {args.dtype}{'+u32 payload' if args.payload else ''} keys sharded {world}x ({pow2(n)} per GPU, {shards}), RCCL histogram all-gather + key all-to-all over xGMI, {args.radix_bits}-bit digits"
         if total_keys == 1 << 30 and args.dtype == "uint32" and not args.payload and args.radix_bits == 4 and one_dataset and kind == "Random":
             workload += " [BASELINE config 4]" if world == 8 else f" [BASELINE config 4's input and size over {world} ranks]"
+    traffic, traffic_note = load_traffic(workload)
     line = {
         "metric": METRIC,
         "value": round(total_keys / (elapsed / args.steps) * 1e-6, 1),
@@ -419,12 +448,13 @@ def main() -> None:
         "data": "synthetic",
         "config": {"workload": workload, "keys_per_gpu": n, "total_keys": total_keys,
                    "parallelism": "single GPU" if not sharded else (
-                       f"msd-partition[{sorter.last_path}] x{world} + peer stores into the owners' receive buffers + local LSD sort" if sorter.last_path == "waves-p2p"
-                       else f"msd-partition[{sorter.last_path}] x{world} + all_to_all (RCCL) + local LSD sort"),
+                       f"msd-partition[{sorter.last_path}] x{world}" + (f", top {sorter.partition_bits} bits = {(1 << sorter.partition_bits) // world} waves per rank" if waves else "")
+                       + (" + peer stores into the owners' receive buffers (one push + fence per wave)" if sorter.last_path == "waves-p2p" else " + all_to_all (RCCL)")
+                       + " + local LSD sort"),
                    "verified": verified},
         "roofline": {
             "bound": "hbm", "kernel": "reorder_kernel" if args.radix_bits == 4 else "reorder8_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": load_traffic(workload),
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
             "algorithmic_bytes_per_launch": scatter_bytes, "avg_launch_ms": round(reorder_ms, 5),
             "launches_per_step": launches_per_step,
         },

@@ -267,33 +267,15 @@ int rsx_partition_scatter(rsx_engine* e, const void* d_keys, const uint32_t* d_p
 int rsx_sample_keys(rsx_engine* e, const void* d_keys, uint64_t n, uint32_t count, uint64_t* samples);
 int rsx_partition_count_split(rsx_engine* e, const void* d_keys, uint64_t n, const uint64_t* splitters, int nsplit, uint64_t* bucket_counts);
 int rsx_partition_scatter_split(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n, void* d_keys_out, uint32_t* d_payload_out);
-/* Wave-major partition (pipelined multi-GPU exchange; world = 1, 2, 4, 8 or 16 ranks owning k = 16/world
- * consecutive top-nibble buckets each): bucket b = rank*k + wave is placed at position wave*world + rank,
- * so that each of the k "waves" holds one bucket per rank, contiguous and in rank order — wave w can be
- * exchanged with one all-to-all and sorted (all its keys at a rank share the top nibble: the last LSD
- * pass is not needed) while wave w+1 is still in flight.  counts[16] come back in that order.
- * rsx_sort_from_to: rsx_sort_from over passes [first_pass, last_pass) whose last pass writes to the
- * caller's d_keys_out / d_payload_out (any alignment), e.g. at an offset inside the final array. */
-int rsx_partition_count_waves(rsx_engine* e, const void* d_keys, uint64_t n, int world, uint64_t* bucket_counts);
-/* The same count with the 16 sizes left in DEVICE memory (d_bucket_counts, 16 x uint64) and no host synchronisation: the caller
- * hands that buffer straight to the collective that exchanges the counts (one host round trip per step instead of three).
- * rsx_partition_scatter_waves follows as after rsx_partition_count_waves. */
-int rsx_partition_count_waves_device(rsx_engine* e, const void* d_keys, uint64_t n, int world, uint64_t* d_bucket_counts);
-int rsx_partition_scatter_waves(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n, void* d_keys_out, uint32_t* d_payload_out);
+/* rsx_sort_from_to: rsx_sort_from over passes [first_pass, last_pass) (4-bit pass units, whatever the digit width of the chain) whose last pass
+ * writes to the caller's d_keys_out / d_payload_out (any alignment), e.g. at an offset inside the final array — the local sort of one
+ * wave of the sharded sort, whose keys share their top bits. */
 int rsx_sort_from_to(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n, int first_pass, int last_pass, void* d_keys_out,
                      uint32_t* d_payload_out);
-/* Peer-store exchange (a selectable alternative to the all-to-all of the pipelined path): the wave-major scatter writes every bucket
- * STRAIGHT into the receive buffer of the rank that owns it — no staging write, no re-read, no collective on the data path.
- * rsx_partition_scatter_waves_peer follows rsx_partition_count_waves[_device] like rsx_partition_scatter_waves; peer_keys[p] (p = 0..15,
- * wave-major position = wave * world + destination rank) is the address where THIS rank's keys of bucket p begin in the destination's
- * buffer (the caller derives it from the gathered count table: destination base + keys of earlier waves + keys of lower-ranked sources
- * in that wave); peer_payload likewise for payload engines.  Addresses need the alignment of one element only.  Asynchronous; the
- * destinations may read their buffers once every source's scatter has finished (the caller's cross-rank barrier on the stream).
- * Receive buffers other ranks can write to: rsx_peer_alloc (hipMalloc + an IPC handle to hand to the other PROCESSES, which map it
- * with rsx_peer_open / rsx_peer_close — lazy peer access over xGMI); ranks that are threads of one process use the pointer itself
- * (rsx_peer_enable once per other device). */
+/* Receive buffers other ranks can write to (the peer-store exchange below): rsx_peer_alloc (hipMalloc + an IPC handle to hand to the other
+ * PROCESSES, which map it with rsx_peer_open / rsx_peer_close — peer access over xGMI); ranks that are threads of one process use the
+ * pointer itself (after rsx_peer_enable, once per other device). */
 #define RSX_IPC_HANDLE_BYTES 64
-int rsx_partition_scatter_waves_peer(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n, void* const* peer_keys, uint32_t* const* peer_payload);
 int rsx_peer_alloc(rsx_engine* e, uint64_t bytes, void** d_ptr, void* ipc_handle /* RSX_IPC_HANDLE_BYTES bytes, or NULL */);
 int rsx_peer_free(rsx_engine* e, void* d_ptr);
 int rsx_peer_open(rsx_engine* e, const void* ipc_handle, void** d_ptr);
@@ -315,11 +297,14 @@ int rsx_peer_enable(rsx_engine* e, int peer_device);
  *                    order), what this rank receives per wave, every rank's load, and the capacity verdict — then copies the host's part to
  *                    pinned memory.  rsx_msd_plan_wait blocks the HOST until that copy has landed (the device never waits for the host) and
  *                    returns it: wave_start / wave_count (2^bits / world entries, in keys, THIS rank's receive buffer), loads (world entries),
- *                    verdict (0 = fits; bit r set = rank r's buffers are too small — then no push writes anything, on any rank).
+ *                    verdict (0 = go; bit r = rank r's buffers are too small; bit 32 + r = rank r's status word, [.. + cap_at + 2] of its row, was
+ *                    non-zero: its engine reported an error of an earlier step — non-zero on one rank is non-zero on all, and no push writes anything).
  *   rsx_msd_push     wave `wave`: copies this rank's segments of that wave from staging straight into the destinations' receive buffers:
  *                    d_peer_keys / d_peer_payload = DEVICE arrays of `world` base addresses as THIS rank addresses them (rsx_peer_alloc /
  *                    rsx_peer_open / rsx_peer_enable).  `parts` workgroups per destination (<= 0: 16): a link-bound copy that leaves the CUs to
- *                    the local sorts.  The caller fences the wave across ranks (one tiny all_reduce, or its own flags) before sorting it.
+ *                    the local sorts.  hip_stream (NULL = the engine's): the stream the copy is enqueued on — a second stream lets wave w + 1
+ *                    travel while wave w is sorted on the engine's; the call makes it wait for the plan and for rsx_msd_scatter itself.
+ *                    The caller fences the wave across ranks (one tiny all_reduce, or its own flags) before sorting it.
  * Plumbing for hosts that do not link HIP themselves: rsx_copy_to_device / _from_device / _on_device (asynchronous on the engine's
  * stream; pageable host memory serialises, pin it with rsx_pin_host) and rsx_wait_for (e's stream waits for everything enqueued on
  * other's stream so far — engines of one process, any devices). */
@@ -327,7 +312,8 @@ int rsx_msd_count(rsx_engine* e, const void* d_keys, uint64_t n, int bits, int w
 int rsx_msd_scatter(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n, void* d_staging, uint32_t* d_staging_payload);
 int rsx_msd_plan(rsx_engine* e, const uint64_t* d_table, uint32_t stride, uint32_t cap_at, int rank, void* hip_stream);
 int rsx_msd_plan_wait(rsx_engine* e, uint64_t* wave_start, uint64_t* wave_count, uint64_t* loads, uint64_t* verdict);
-int rsx_msd_push(rsx_engine* e, int wave, const void* d_staging, const uint32_t* d_staging_payload, const uint64_t* d_peer_keys, const uint64_t* d_peer_payload, int parts);
+int rsx_msd_push(rsx_engine* e, int wave, const void* d_staging, const uint32_t* d_staging_payload, const uint64_t* d_peer_keys, const uint64_t* d_peer_payload, int parts,
+                 void* hip_stream);
 int rsx_copy_to_device(rsx_engine* e, void* d_dst, const void* host_src, uint64_t bytes);
 int rsx_copy_from_device(rsx_engine* e, void* host_dst, const void* d_src, uint64_t bytes);
 int rsx_copy_on_device(rsx_engine* e, void* d_dst, const void* d_src, uint64_t bytes);

@@ -43,7 +43,7 @@ SYMBOLS = [
     "rsx_create", "rsx_destroy", "rsx_set_stream", "rsx_get_stream", "rsx_set_option", "rsx_get_geometry", "rsx_resize",
     "rsx_upload", "rsx_fill_pad", "rsx_download", "rsx_pin_host", "rsx_unpin_host", "rsx_pipeline_submit", "rsx_pipeline_wait", "rsx_host_device_pointer",
     "rsx_histogram", "rsx_scan", "rsx_paste", "rsx_reorder", "rsx_sort", "rsx_sync", "rsx_check_status",
-    "rsx_sort_from", "rsx_partition", "rsx_partition_count", "rsx_partition_scatter", "rsx_sample_keys", "rsx_partition_count_split", "rsx_partition_scatter_split", "rsx_partition_count_waves", "rsx_partition_count_waves_device", "rsx_partition_scatter_waves", "rsx_partition_scatter_waves_peer", "rsx_peer_alloc", "rsx_peer_free", "rsx_peer_open", "rsx_peer_close", "rsx_peer_enable", "rsx_sort_from_to", "rsx_msd_count", "rsx_msd_scatter", "rsx_msd_plan", "rsx_msd_plan_wait", "rsx_msd_push", "rsx_copy_to_device", "rsx_copy_from_device", "rsx_copy_on_device", "rsx_wait_for", "rsx_key_range", "rsx_partition_range", "rsx_result_device", "rsx_copy_result", "rsx_tile_map", "rsx_timings",
+    "rsx_sort_from", "rsx_partition", "rsx_partition_count", "rsx_partition_scatter", "rsx_sample_keys", "rsx_partition_count_split", "rsx_partition_scatter_split", "rsx_peer_alloc", "rsx_peer_free", "rsx_peer_open", "rsx_peer_close", "rsx_peer_enable", "rsx_sort_from_to", "rsx_msd_count", "rsx_msd_scatter", "rsx_msd_plan", "rsx_msd_plan_wait", "rsx_msd_push", "rsx_copy_to_device", "rsx_copy_from_device", "rsx_copy_on_device", "rsx_wait_for", "rsx_key_range", "rsx_partition_range", "rsx_result_device", "rsx_copy_result", "rsx_tile_map", "rsx_timings",
 ]
 
 
@@ -142,10 +142,6 @@ def load_library() -> C.CDLL:
         "rsx_sample_keys": ([P, P, U64, C.c_uint32, C.POINTER(U64)], I),
         "rsx_partition_count_split": ([P, P, U64, C.POINTER(U64), I, C.POINTER(U64)], I),
         "rsx_partition_scatter_split": ([P, P, P, U64, P, P], I),
-        "rsx_partition_count_waves": ([P, P, U64, I, C.POINTER(U64)], I),
-        "rsx_partition_count_waves_device": ([P, P, U64, I, P], I),
-        "rsx_partition_scatter_waves": ([P, P, P, U64, P, P], I),
-        "rsx_partition_scatter_waves_peer": ([P, P, P, U64, C.POINTER(P), C.POINTER(P)], I),
         "rsx_peer_alloc": ([P, U64, C.POINTER(P), P], I),
         "rsx_peer_free": ([P, P], I),
         "rsx_peer_open": ([P, P, C.POINTER(P)], I),
@@ -156,7 +152,7 @@ def load_library() -> C.CDLL:
         "rsx_msd_scatter": ([P, P, P, U64, P, P], I),
         "rsx_msd_plan": ([P, P, C.c_uint32, C.c_uint32, I, P], I),
         "rsx_msd_plan_wait": ([P, C.POINTER(U64), C.POINTER(U64), C.POINTER(U64), C.POINTER(U64)], I),
-        "rsx_msd_push": ([P, I, P, P, P, P, I], I),
+        "rsx_msd_push": ([P, I, P, P, P, P, I, P], I),
         "rsx_copy_to_device": ([P, P, P, U64], I),
         "rsx_copy_from_device": ([P, P, P, U64], I),
         "rsx_copy_on_device": ([P, P, P, U64], I),
@@ -229,6 +225,7 @@ class Engine:
         kb, sg = _KEY_DTYPES[self.dtype.name]
         self.payload = bool(payload)
         self.capacity = int(capacity)
+        self.device = int(device)
         self._h = C.c_void_p()
         rc = self.lib.rsx_create(C.byref(self._h), device, kb, sg, int(self.payload), self.capacity)
         if rc != 0:
@@ -385,27 +382,6 @@ class Engine:
             self._h, C.c_void_p(d_keys), C.c_void_p(d_payload) if d_payload else None, n,
             C.c_void_p(d_keys_out), C.c_void_p(d_payload_out) if d_payload_out else None), "rsx_partition_scatter_split")
 
-    def partition_count_waves(self, d_keys: int, n: int, world: int) -> list[int]:
-        counts = (C.c_uint64 * 16)()
-        self._check(self.lib.rsx_partition_count_waves(self._h, C.c_void_p(d_keys), n, world, counts), "rsx_partition_count_waves")
-        return [int(v) for v in counts]
-
-    def partition_count_waves_device(self, d_keys: int, n: int, world: int, d_counts: int) -> None:
-        """The 16 wave-major bucket sizes into device memory (16 x uint64 at d_counts), asynchronously: no host round trip."""
-        self._check(self.lib.rsx_partition_count_waves_device(self._h, C.c_void_p(d_keys), n, world, C.c_void_p(d_counts)), "rsx_partition_count_waves_device")
-
-    def partition_scatter_waves(self, d_keys: int, n: int, d_keys_out: int, d_payload: int | None = None, d_payload_out: int | None = None) -> None:
-        self._check(self.lib.rsx_partition_scatter_waves(
-            self._h, C.c_void_p(d_keys), C.c_void_p(d_payload) if d_payload else None, n,
-            C.c_void_p(d_keys_out), C.c_void_p(d_payload_out) if d_payload_out else None), "rsx_partition_scatter_waves")
-
-    def partition_scatter_waves_peer(self, d_keys: int, n: int, peer_keys: list[int], d_payload: int | None = None, peer_payload: list[int] | None = None) -> None:
-        """The wave-major scatter with every bucket written straight to its own destination address (16 of them)."""
-        pk = (C.c_void_p * 16)(*peer_keys)
-        pp = (C.c_void_p * 16)(*peer_payload) if peer_payload is not None else None
-        self._check(self.lib.rsx_partition_scatter_waves_peer(self._h, C.c_void_p(d_keys), C.c_void_p(d_payload) if d_payload else None, n, pk, pp),
-                    "rsx_partition_scatter_waves_peer")
-
     def peer_alloc(self, nbytes: int) -> tuple[int, bytes]:
         """A device buffer other ranks may write to: (address, IPC handle for other processes)."""
         p, h = C.c_void_p(), C.create_string_buffer(64)
@@ -451,9 +427,12 @@ class Engine:
         self._check(self.lib.rsx_msd_plan_wait(self._h, ws, wc, ld, C.byref(v)), "rsx_msd_plan_wait")
         return [int(x) for x in ws], [int(x) for x in wc], [int(x) for x in ld], int(v.value)
 
-    def msd_push(self, wave: int, d_staging: int, d_peer_keys: int, d_staging_payload: int | None = None, d_peer_payload: int | None = None, parts: int = 0) -> None:
+    def msd_push(self, wave: int, d_staging: int, d_peer_keys: int, d_staging_payload: int | None = None, d_peer_payload: int | None = None, parts: int = 0,
+                 hip_stream: int = 0) -> None:
+        """Wave `wave` of the staging buffer into the owners' receive buffers, on hip_stream (0: the engine's stream)."""
         self._check(self.lib.rsx_msd_push(self._h, wave, C.c_void_p(d_staging), C.c_void_p(d_staging_payload) if d_staging_payload else None,
-                                          C.c_void_p(d_peer_keys), C.c_void_p(d_peer_payload) if d_peer_payload else None, parts), "rsx_msd_push")
+                                          C.c_void_p(d_peer_keys), C.c_void_p(d_peer_payload) if d_peer_payload else None, parts,
+                                          C.c_void_p(hip_stream) if hip_stream else None), "rsx_msd_push")
 
     def wait_for(self, other: "Engine") -> None:
         """This engine's stream waits for everything enqueued on `other`'s stream so far."""

@@ -156,7 +156,6 @@ struct rsx_engine {
     int ref_diag = 0;                           // RSX_OPT_REF_DIAGNOSTICS
     uint64_t splitters[rsx::kMaxSplitters] = {};   // splitters of the current split partition, unsigned sort order
     uint32_t nsplit = 0;
-    uint32_t wave_rot = 0;                      // non-zero only inside the wave-major partition calls
     bool result_external = false;               // the last sort wrote into the caller's buffer (rsx_sort_from_to): nothing to download
     void* final_keys_out = nullptr;             // rsx_sort_from_to: where the last pass writes
     uint32_t* final_perm_out = nullptr;
@@ -178,12 +177,13 @@ struct rsx_engine {
     int alloc_mode = 0;         // 0 hipMalloc; 1 chunks mapped in creation order; 2 chunks mapped in a shuffled order
     size_t alloc_chunk = 0;     // chunk bytes (env RSX_ALLOC_CHUNK_MB; 0 = 32 MiB)
 #endif
-    unsigned long long* peer_dev = nullptr;     // peer-store exchange: 16 key + 16 payload destination addresses (allocated on first use)
     // exchange step of the sharded sort on the top B <= 8 bits (capi_msd.inc; all allocated on first use)
     rsx::MsdPlan* msd_plan = nullptr;           // device: segments of this rank per (wave, destination), what it receives per wave, loads, verdict
     rsx::MsdPlan* msd_plan_host = nullptr;      // pinned mirror of the part the host needs
     uint32_t* msd_starts = nullptr;             // device: first staging slot of each of the 256 fine buckets, wave-major order
     hipEvent_t msd_event = nullptr;             // the plan (and its copy to the host) is complete
+    hipEvent_t msd_scatter_event = nullptr;     // rsx_msd_scatter has filled the staging buffer (pushes on another stream wait for it)
+    bool msd_scattered = false;
     hipEvent_t order_event = nullptr;           // rsx_wait_for: "everything enqueued on this engine's stream so far"
     const void* msd_keys = nullptr;             // rsx_msd_count left table8 / cbase8 for exactly this input ...
     uint64_t msd_n = 0;
@@ -338,7 +338,6 @@ rsx::SplitSet<Key> split_set(const rsx_engine* e, uint32_t nsplit)
     rsx::SplitSet<Key> set{};
     for (uint32_t k = 0; k < nsplit && k < static_cast<uint32_t>(rsx::kMaxSplitters); ++k) set.s[k] = static_cast<Key>(e->splitters[k]);
     set.n = nsplit;
-    set.rot = nsplit ? 0u : e->wave_rot;
     return set;
 }
 
@@ -471,8 +470,7 @@ int launch_paste(rsx_engine* e, uint64_t count)
 template <typename Key, bool PAYLOAD, bool LOOKAHEAD, bool RANGED = false, int KPT = kKeysPerThread, int THREADS = kTileThreads>
 int launch_reorder_t(rsx_engine* e, const void* in, void* out, const uint32_t* pin, uint32_t* pout, uint64_t count, int shift,
                      uint32_t mask, int next_shift, Key lo = Key{0}, Key mul = Key{0}, uint32_t nsplit = 0,
-                     rsx::SelfScanArgs self = rsx::SelfScanArgs{nullptr, nullptr, nullptr}, uint32_t* next_counts = nullptr,
-                     rsx::PeerArgs peer = rsx::PeerArgs{nullptr, nullptr})
+                     rsx::SelfScanArgs self = rsx::SelfScanArgs{nullptr, nullptr, nullptr}, uint32_t* next_counts = nullptr)
 {
     using L = rsx::ReorderLayout<Key, THREADS, KPT>;
     const Grid g = grid_for(e, count, THREADS * KPT);
@@ -489,7 +487,7 @@ int launch_reorder_t(rsx_engine* e, const void* in, void* out, const uint32_t* p
 #else
                        static_cast<const uint32_t*>(nullptr),      // (folding the paste into the scatter — it adds globsum[group] itself — was measured 3 % slower and removed in round 4)
 #endif
-                       lo, mul, split_set<Key>(e, nsplit), self, peer);
+                       lo, mul, split_set<Key>(e, nsplit), self);
     RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
     return RSX_OK;
 }
@@ -848,6 +846,7 @@ Scan8Shape scan8_shape(uint32_t ntiles)
 template <typename Key>
 int launch_count8(rsx_engine* e, const void* in, uint64_t count, const Grid& g, const Scan8Shape& s, int shift)
 {
+    e->msd_keys = nullptr;              // the 8-bit tables are about to be overwritten: a pending rsx_msd_count is void
     {
         Bracket b(e, PH_HISTO);
         hipLaunchKernelGGL((rsx::histogram8_kernel<Key, kTileThreads, kKeysPerThread>), dim3(g.blocks), dim3(kTileThreads), 0, e->stream,
@@ -1445,11 +1444,11 @@ int rsx_destroy(rsx_engine* e)
     if (e->cbase8 && hipFree(e->cbase8) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->scan_timeout_host && hipHostFree(e->scan_timeout_host) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->starts_dev && hipFree(e->starts_dev) != hipSuccess) status = RSX_CLEANUP_FAILED;
-    if (e->peer_dev && hipFree(e->peer_dev) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->msd_plan && hipFree(e->msd_plan) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->msd_starts && hipFree(e->msd_starts) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->msd_plan_host && hipHostFree(e->msd_plan_host) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->msd_event) (void)hipEventDestroy(e->msd_event);
+    if (e->msd_scatter_event) (void)hipEventDestroy(e->msd_scatter_event);
     if (e->order_event) (void)hipEventDestroy(e->order_event);
     if (e->range_dev && hipFree(e->range_dev) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->ref_table && hipFree(e->ref_table) != hipSuccess) status = RSX_CLEANUP_FAILED;
@@ -2094,146 +2093,6 @@ int rsx_partition_scatter_split(rsx_engine* e, const void* d_keys, const uint32_
     }
     return with_payload ? launch_reorder_t<uint64_t, true, false, true>(e, d_keys, d_keys_out, pin, pout, n, 0, RSX_RADIX - 1, 0, 0ull, 0ull, e->nsplit)
                         : launch_reorder_t<uint64_t, false, false, true>(e, d_keys, d_keys_out, nullptr, nullptr, n, 0, RSX_RADIX - 1, 0, 0ull, 0ull, e->nsplit);
-}
-
-namespace {
-// rot such that world = 16 >> rot; -1 if world is not 1, 2, 4, 8 or 16
-int wave_rot_of(int world)
-{
-    for (int rot = 0; rot <= RSX_RADIX_BITS; ++rot) {
-        if ((RSX_RADIX >> rot) == world) return rot;
-    }
-    return -1;
-}
-}  // namespace
-
-namespace {
-// histogram of the wave-major buckets + the 16 totals in e->range_dev; nothing leaves the device, nothing synchronises
-int count_waves_enqueue(rsx_engine* e, const void* d_keys, uint64_t n, int rot, const char* who)
-{
-    if (!d_keys || !aligned16(d_keys)) return fail(RSX_HOST_BUFFERS_FAILED, who);
-    if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
-    const int shift = e->key_bytes * 8 - RSX_RADIX_BITS;
-    e->wave_rot = static_cast<uint32_t>(rot % RSX_RADIX_BITS);        // world 1: 16 waves of one bucket, identity order
-    const int rc = RSX_BY_KEY(e, (launch_histogram<uint32_t, true>(e, d_keys, n, shift, RSX_RADIX - 1, 0u, 0u, 0)),
-                              (launch_histogram<uint64_t, true>(e, d_keys, n, shift, RSX_RADIX - 1, 0ull, 0ull, 0)));
-    e->wave_rot = 0;
-    if (rc != RSX_OK) return rc;
-    hipLaunchKernelGGL(rsx::digit_totals_kernel, dim3(RSX_RADIX), dim3(256), 0, e->stream, e->table, static_cast<uint32_t>(e->ntiles(n)), e->range_dev);
-    RSX_TRY(hipGetLastError(), RSX_CALCULATION_FAILED);
-    return RSX_OK;
-}
-}  // namespace
-
-int rsx_partition_count_waves(rsx_engine* e, const void* d_keys, uint64_t n, int world, uint64_t* bucket_counts)
-{
-    if (!e || !bucket_counts) return fail(RSX_CALCULATION_FAILED, "rsx_partition_count_waves: null argument");
-    const int rot = wave_rot_of(world);
-    if (rot < 0) return fail(RSX_CALCULATION_FAILED, "rsx_partition_count_waves: world must be 1, 2, 4, 8 or 16");
-    if (n > e->capacity) return fail(RSX_RESIZE_FAILED, "rsx_partition_count_waves: beyond capacity");
-    for (int d = 0; d < RSX_RADIX; ++d) bucket_counts[d] = 0;
-    if (n == 0) return RSX_OK;
-    const int rc = count_waves_enqueue(e, d_keys, n, rot, "rsx_partition_count_waves: keys must be a 16-byte aligned device pointer");
-    if (rc != RSX_OK) return rc;
-    RSX_TRY(hipMemcpyAsync(e->range_host, e->range_dev, RSX_RADIX * 8, hipMemcpyDeviceToHost, e->stream), RSX_CALCULATION_FAILED);
-    RSX_TRY(hipStreamSynchronize(e->stream), RSX_CALCULATION_FAILED);
-    for (int d = 0; d < RSX_RADIX; ++d) bucket_counts[d] = e->range_host[d];
-    e->counted_keys = d_keys;
-    e->counted_n = n;
-    e->counted_shift = -2;            // marks a wave-major count
-    e->counted_bits = rot;
-    return RSX_OK;
-}
-
-int rsx_partition_count_waves_device(rsx_engine* e, const void* d_keys, uint64_t n, int world, uint64_t* d_bucket_counts)
-{
-    if (!e || !d_bucket_counts) return fail(RSX_CALCULATION_FAILED, "rsx_partition_count_waves_device: null argument");
-    const int rot = wave_rot_of(world);
-    if (rot < 0) return fail(RSX_CALCULATION_FAILED, "rsx_partition_count_waves_device: world must be 1, 2, 4, 8 or 16");
-    if (n > e->capacity) return fail(RSX_RESIZE_FAILED, "rsx_partition_count_waves_device: beyond capacity");
-    if (n == 0) {
-        if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
-        RSX_TRY(hipMemsetAsync(d_bucket_counts, 0, RSX_RADIX * 8, e->stream), RSX_CALCULATION_FAILED);
-        return RSX_OK;
-    }
-    const int rc = count_waves_enqueue(e, d_keys, n, rot, "rsx_partition_count_waves_device: keys must be a 16-byte aligned device pointer");
-    if (rc != RSX_OK) return rc;
-    RSX_TRY(hipMemcpyAsync(d_bucket_counts, e->range_dev, RSX_RADIX * 8, hipMemcpyDeviceToDevice, e->stream), RSX_CALCULATION_FAILED);
-    e->counted_keys = d_keys;
-    e->counted_n = n;
-    e->counted_shift = -2;
-    e->counted_bits = rot;
-    return RSX_OK;
-}
-
-namespace {
-// scan + paste + stable scatter of a wave-major count (rsx_partition_count_waves*): into the caller's one buffer, or — `peer` set —
-// bucket by bucket into 16 destination addresses
-int scatter_waves(rsx_engine* e, const char* who, const void* d_keys, const uint32_t* d_payload, uint64_t n, void* d_keys_out, uint32_t* d_payload_out,
-                  rsx::PeerArgs peer)
-{
-    if (d_keys != e->counted_keys || n != e->counted_n || e->counted_shift != -2)
-        return fail(RSX_CALCULATION_FAILED, (std::string(who) + ": must follow rsx_partition_count_waves on the same keys").c_str());
-    e->counted_keys = nullptr;
-    if (!peer.keys && (!d_keys_out || !aligned16(d_keys_out))) return fail(RSX_HOST_BUFFERS_FAILED, (std::string(who) + ": output must be a 16-byte aligned device pointer").c_str());
-    const bool with_payload = e->has_payload && d_payload && (d_payload_out || peer.pays);
-    if (e->has_payload && !with_payload) return fail(RSX_HOST_BUFFERS_FAILED, (std::string(who) + ": payload engine needs payload buffers").c_str());
-    if (with_payload && !aligned16(d_payload)) return fail(RSX_HOST_BUFFERS_FAILED, (std::string(who) + ": the payload input must be 16-byte aligned (it is read 16 bytes per lane)").c_str());
-    int rc = launch_scan(e, n);
-    if (rc == RSX_OK) rc = launch_paste(e, n);
-    if (rc != RSX_OK) return rc;
-    const uint32_t* pin = with_payload ? d_payload : nullptr;
-    uint32_t* pout = with_payload ? d_payload_out : nullptr;
-    const int shift = e->key_bytes * 8 - RSX_RADIX_BITS;
-    e->wave_rot = static_cast<uint32_t>(e->counted_bits % RSX_RADIX_BITS);
-    const rsx::SelfScanArgs none{nullptr, nullptr, nullptr};
-    if (e->key_bytes == 4) {
-        rc = with_payload ? launch_reorder_t<uint32_t, true, false, true>(e, d_keys, d_keys_out, pin, pout, n, shift, RSX_RADIX - 1, 0, 0u, 0u, 0, none, nullptr, peer)
-                          : launch_reorder_t<uint32_t, false, false, true>(e, d_keys, d_keys_out, nullptr, nullptr, n, shift, RSX_RADIX - 1, 0, 0u, 0u, 0, none, nullptr, peer);
-    } else {
-        rc = with_payload ? launch_reorder_t<uint64_t, true, false, true>(e, d_keys, d_keys_out, pin, pout, n, shift, RSX_RADIX - 1, 0, 0ull, 0ull, 0, none, nullptr, peer)
-                          : launch_reorder_t<uint64_t, false, false, true>(e, d_keys, d_keys_out, nullptr, nullptr, n, shift, RSX_RADIX - 1, 0, 0ull, 0ull, 0, none, nullptr, peer);
-    }
-    e->wave_rot = 0;
-    return rc;
-}
-}  // namespace
-
-int rsx_partition_scatter_waves(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n, void* d_keys_out, uint32_t* d_payload_out)
-{
-    if (!e) return fail(RSX_CALCULATION_FAILED, "rsx_partition_scatter_waves: null engine");
-    if (n == 0) {
-        e->counted_keys = nullptr;
-        return RSX_OK;
-    }
-    if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
-    return scatter_waves(e, "rsx_partition_scatter_waves", d_keys, d_payload, n, d_keys_out, d_payload_out, rsx::PeerArgs{nullptr, nullptr});
-}
-
-int rsx_partition_scatter_waves_peer(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n, void* const* peer_keys, uint32_t* const* peer_payload)
-{
-    if (!e || !peer_keys) return fail(RSX_CALCULATION_FAILED, "rsx_partition_scatter_waves_peer: null argument");
-    if (e->has_payload && !peer_payload) return fail(RSX_HOST_BUFFERS_FAILED, "rsx_partition_scatter_waves_peer: payload engine needs payload destinations");
-    if (n == 0) {
-        e->counted_keys = nullptr;
-        return RSX_OK;
-    }
-    if (bind_device(e, RSX_CALCULATION_FAILED) != RSX_OK) return RSX_CALCULATION_FAILED;
-    if (!e->peer_dev) RSX_TRY(hipMalloc(reinterpret_cast<void**>(&e->peer_dev), 2 * RSX_RADIX * 8), RSX_INITIALIZATION_FAILED);
-    // (from pageable memory: the runtime has captured the 256 bytes when the call returns, so the array may live on this stack)
-    unsigned long long addr[2 * RSX_RADIX] = {};
-    for (int b = 0; b < RSX_RADIX; ++b) {
-        addr[b] = reinterpret_cast<unsigned long long>(peer_keys[b]);
-        addr[RSX_RADIX + b] = e->has_payload ? reinterpret_cast<unsigned long long>(peer_payload[b]) : 0ull;
-        const bool needed = true;       // a bucket without keys is never dereferenced, but a null address for one that has keys would fault: refuse all nulls
-        if (needed && (!addr[b] || (e->has_payload && !addr[RSX_RADIX + b])))
-            return fail(RSX_HOST_BUFFERS_FAILED, "rsx_partition_scatter_waves_peer: null destination address");
-        if (addr[b] % static_cast<unsigned>(e->key_bytes) || addr[RSX_RADIX + b] % 4u)
-            return fail(RSX_HOST_BUFFERS_FAILED, "rsx_partition_scatter_waves_peer: misaligned destination address");
-    }
-    RSX_TRY(hipMemcpyAsync(e->peer_dev, addr, sizeof(addr), hipMemcpyHostToDevice, e->stream), RSX_CALCULATION_FAILED);
-    return scatter_waves(e, "rsx_partition_scatter_waves_peer", d_keys, d_payload, n, nullptr, nullptr,
-                         rsx::PeerArgs{e->peer_dev, e->has_payload ? e->peer_dev + RSX_RADIX : nullptr});
 }
 
 // ---- peer-visible buffers (the receive side of the peer-store exchange) ----------------------------------------------------

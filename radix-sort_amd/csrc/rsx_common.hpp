@@ -73,17 +73,7 @@ template <typename Key>
 struct SplitSet {
     Key s[kMaxSplitters];
     uint32_t n;
-    uint32_t rot;      // n == 0 only: rotate the 4-bit range bucket right by `rot` (wave-major bucket order, see wave_major)
 };
-
-// Wave-major order of the 16 top-nibble buckets for world = 16 >> rot ranks owning 1 << rot
-// consecutive buckets each: bucket b = rank * k + wave  ->  wave * world + rank, which for these
-// powers of two is a rotation of the nibble.  All the buckets of one wave then sit next to each
-// other, in rank order, so that wave can leave in one all-to-all while the next is still being sorted.
-__device__ __forceinline__ uint32_t wave_major(uint32_t b, uint32_t rot)
-{
-    return ((b >> rot) | (b << (kRadixBits - rot))) & static_cast<uint32_t>(kRadix - 1);
-}
 
 template <typename Key>
 __device__ __forceinline__ uint32_t splitter_bucket(Key x, const SplitSet<Key>& set)

@@ -27,8 +27,7 @@ __global__ __launch_bounds__(THREADS) void histogram_kernel(const Key* __restric
             if (split.n) {
                 return splitter_bucket(static_cast<Key>(key ^ flip), split);
             }
-            const uint32_t b = ranged_bucket(static_cast<Key>((key ^ flip) - lo), shift, mul, mask);
-            return split.rot ? wave_major(b, split.rot) : b;
+            return ranged_bucket(static_cast<Key>((key ^ flip) - lo), shift, mul, mask);
         } else {
             return digit_of(key, shift, flip, mask);
         }

@@ -98,12 +98,13 @@ struct MsdPlan {
     unsigned long long wave_start[kRadix8];  // what THIS rank receives: first slot of wave w in its receive buffer (16-byte aligned) ...
     unsigned long long wave_count[kRadix8];  // ... and its keys
     unsigned long long load[kMsdMaxWorld];   // keys every rank ends up with
-    unsigned long long verdict;              // 0: every rank's buffers hold their share; otherwise bit r = rank r overflows (no push writes anything)
+    unsigned long long verdict;              // 0: go.  Bit r (r < 16) = rank r's buffers are too small; bit 32 + r = rank r reported a non-zero status word
+                                             // (table[r * stride + cap_at + 2]: an engine error of an earlier step).  Non-zero: no push writes anything.
     unsigned long long waves;                // 2^bits / world
 };
 
 // table[src * stride + b] = keys of source rank src in coarse bucket b (b < nbuckets = 2^bits, natural order; sub_shift = 8 - bits); table[src * stride + cap_at] / [cap_at + 1] = that
-// rank's receive / output capacity in keys.  Receive layout at every destination: the waves follow each other, each starting on a 16-byte
+// rank's receive / output capacity in keys, [cap_at + 2] = its status word (non-zero: that rank's engine reported an error; everybody stops together).  Receive layout at every destination: the waves follow each other, each starting on a 16-byte
 // boundary (`align` keys: the local sort loads 16 bytes per lane), and inside a wave the sources follow each other in rank order.
 __global__ __launch_bounds__(kRadix8) void msd_layout_kernel(const unsigned long long* __restrict__ table, uint32_t stride, uint32_t cap_at, uint32_t nbuckets,
                                                              uint32_t world, uint32_t rank, uint32_t align, uint32_t sub_shift,
@@ -148,6 +149,9 @@ __global__ __launch_bounds__(kRadix8) void msd_layout_kernel(const unsigned long
         const unsigned long long recv_cap = table[static_cast<uint64_t>(dst) * stride + cap_at], out_cap = table[static_cast<uint64_t>(dst) * stride + cap_at + 1];
         if (at > recv_cap || total > out_cap || at > 0xFFFFFFFFull) {
             atomicOr(&bad, 1ull << dst);
+        }
+        if (table[static_cast<uint64_t>(dst) * stride + cap_at + 2] != 0ull) {
+            atomicOr(&bad, 1ull << (32 + dst));
         }
     }
     __syncthreads();

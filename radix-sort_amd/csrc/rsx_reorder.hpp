@@ -159,15 +159,6 @@ struct SelfScanArgs {
     uint32_t* table_out;         // last pass: leave the tile's 16 first slots in table[digit][tile] as the scan would
 };
 
-// Peer-store exchange of the sharded sort (RANGED launches only, `keys != nullptr`): bucket b does not go to `out` but to the
-// buffer keys[b] (payload: pays[b]) — device arrays of 16 addresses, each naming where THIS rank's keys of bucket b begin in the
-// receive buffer of the rank that owns the bucket (peer-mapped memory of another GPU over xGMI, or plain local memory).  A key's
-// index inside its bucket is its global slot minus the bucket's first slot, table[b][0].
-struct PeerArgs {
-    const unsigned long long* keys;      // nullptr: everything goes to `out` / `pout`
-    const unsigned long long* pays;
-};
-
 // Inline table scan (mid-size sorts, INLINE_SCAN kernels): the launch has no scan kernel in front of it.  Its first `ngroups`
 // workgroups (in dispatch order the first to start) each scan one group of 256 tiles of THIS pass's raw counts before turning to their
 // own tile — the fused scan's workgroup body (fused_scan_group), with the finished table entries published write-through and a
@@ -205,8 +196,7 @@ __global__ __launch_bounds__(THREADS, (INLINE_SCAN ? 3 : reorder_min_waves<Key, 
                                                            uint32_t tiles_per_xcd, int remap, int shift, Key flip, uint32_t mask,
                                                            uint32_t* __restrict__ next_counts, int next_shift,
                                                            const uint32_t* __restrict__ globsum, Key lo, Key mul,
-                                                           SplitSet<Key> split, SelfScanArgs self, PeerArgs peer = PeerArgs{nullptr, nullptr},
-                                                           InlineScanArgs iscan = InlineScanArgs{})
+                                                           SplitSet<Key> split, SelfScanArgs self, InlineScanArgs iscan = InlineScanArgs{})
 {
     static_assert(!INLINE_SCAN || (!RANGED && THREADS == kScanTiles), "the inline scan is the fused scan's workgroup: 256 threads, rsx_sort's passes only");
     using L = ReorderLayout<Key, THREADS, KPT>;
@@ -241,21 +231,6 @@ __global__ __launch_bounds__(THREADS, (INLINE_SCAN ? 3 : reorder_min_waves<Key, 
     }
     // (lds_store_at addresses the staging image from LDS address 0: rsx_create checks once, on the host, that this kernel has no static
     // LDS in front of its dynamic array and that such an array starts at 0 on this device — KERNEL_CREATION_FAILED otherwise)
-    // peer-store launches: the 16 destination addresses (self-scan scratch, unused in RANGED launches; read after several barriers)
-    const bool to_peers = RANGED && peer.keys != nullptr;                 // wave-uniform
-    unsigned long long* peer_k = reinterpret_cast<unsigned long long*>(self_part);
-    unsigned long long* peer_p = peer_k + kRadix;
-    static_assert(((THREADS / kWave) * 2 * kRadix + kRadix) * 4 >= 2 * kRadix * 8, "the peer address tables fit the self-scan scratch");
-    // (loaded here, put into LDS after the key loads have been issued — written at once, the wave would wait for these before it loads its keys)
-    unsigned long long peer_k_mine = 0, peer_p_mine = 0;
-    if constexpr (RANGED) {
-        if (to_peers && tid < static_cast<uint32_t>(kRadix)) {
-            peer_k_mine = peer.keys[tid];
-            if constexpr (PAYLOAD) {
-                peer_p_mine = peer.pays[tid];
-            }
-        }
-    }
     const uint64_t base = static_cast<uint64_t>(tile) * TILE;
     const uint64_t left = n - base;
     const uint32_t valid = left < static_cast<uint64_t>(TILE) ? static_cast<uint32_t>(left) : static_cast<uint32_t>(TILE);
@@ -292,8 +267,7 @@ __global__ __launch_bounds__(THREADS, (INLINE_SCAN ? 3 : reorder_min_waves<Key, 
             if (split.n) {
                 return splitter_bucket(static_cast<Key>(key ^ flip), split);
             }
-            const uint32_t b = ranged_bucket(static_cast<Key>((key ^ flip) - lo), shift, mul, mask);
-            return split.rot ? wave_major(b, split.rot) : b;
+            return ranged_bucket(static_cast<Key>((key ^ flip) - lo), shift, mul, mask);
         } else if constexpr (RAW) {
             return __builtin_amdgcn_ubfe(field_word(key, hi_cur), sh, 4u);
         } else {
@@ -308,20 +282,13 @@ __global__ __launch_bounds__(THREADS, (INLINE_SCAN ? 3 : reorder_min_waves<Key, 
     const uint32_t hl = tid / RAKE_STRIDE;
     // (the pieces of the two table entries stay apart until phase 3 adds them up: summed here, inside the raking threads' branch, the adds and with them
     // the wait for these loads would stand BEFORE the key loads of the wave)
-    uint32_t first_lo = 0, first_hi = 0, group_lo = 0, group_hi = 0, bucket_lo = 0, bucket_hi = 0;
+    uint32_t first_lo = 0, first_hi = 0, group_lo = 0, group_hi = 0;
     const bool self_scan = !RANGED && self.counts != nullptr;      // wave-uniform
     if (rake_head && !self_scan && !INLINE_SCAN) {
         const uint64_t e_lo = static_cast<uint64_t>(hl) * ntiles + tile;
         const uint64_t e_hi = static_cast<uint64_t>(hl + 8) * ntiles + tile;
         first_lo = table[e_lo];
         first_hi = table[e_hi];
-        if constexpr (RANGED) {
-            if (to_peers) {
-                // index inside the bucket instead of the global slot (table[b][0] = the bucket's first slot)
-                bucket_lo = table[static_cast<uint64_t>(hl) * ntiles];
-                bucket_hi = table[static_cast<uint64_t>(hl + 8) * ntiles];
-            }
-        }
         if (globsum) {
             // PasteHistogram folded in: the table holds block-local prefixes, add the scanned
             // sum of the scan group (256 tiles of one digit) each entry lives in (RadixSort.cl:185-197)
@@ -370,14 +337,6 @@ __global__ __launch_bounds__(THREADS, (INLINE_SCAN ? 3 : reorder_min_waves<Key, 
         }
     }
 
-    if constexpr (RANGED) {
-        if (to_peers && tid < static_cast<uint32_t>(kRadix)) {
-            peer_k[tid] = peer_k_mine;
-            if constexpr (PAYLOAD) {
-                peer_p[tid] = peer_p_mine;
-            }
-        }
-    }
     if (self_scan) {
         // (the key loads above are in flight; this is L2-resident table work under their latency)
         // thread (q = tid & 3, r = tid >> 2) reads digits 4q..4q+3 of the rows r, r + 64, ... with 16-byte loads: a wave covers
@@ -570,8 +529,8 @@ __global__ __launch_bounds__(THREADS, (INLINE_SCAN ? 3 : reorder_min_waves<Key, 
         if (rake_head) {
             // `run` is the scanned word of (true digit hl | hl+8, thread 0): the tile-local slot of the
             // tile's first key with that digit.  Stored where phase 5 looks it up: at the RAW digit.
-            first_lo += group_lo - bucket_lo;
-            first_hi += group_hi - bucket_hi;
+            first_lo += group_lo;
+            first_hi += group_hi;
             const uint32_t g_lo = first_lo - (run & 0xFFFFu), g_hi = first_hi - (run >> 16);
             const uint32_t r_lo = hl ^ flip_cur, r_hi = (hl + 8u) ^ flip_cur;
             runs[r_lo] = RunBase{g_lo, (r_lo << 5) - ((first_lo >> L::TILE_SHIFT) << 4)};
@@ -633,7 +592,6 @@ __global__ __launch_bounds__(THREADS, (INLINE_SCAN ? 3 : reorder_min_waves<Key, 
     Key okey[KPT];
     uint32_t g[KPT];
     uint32_t la_idx[LOOKAHEAD ? KPT : 1];
-    uint32_t bucket_of[RANGED ? KPT : 1];
 #pragma unroll
     for (int r = 0; r < KPT; ++r) {
         okey[r] = xk[rd_base + static_cast<uint32_t>(r) * RSTRIDE];
@@ -643,8 +601,7 @@ __global__ __launch_bounds__(THREADS, (INLINE_SCAN ? 3 : reorder_min_waves<Key, 
 #pragma unroll
         for (int r = 0; r < KPT; ++r) {
             if constexpr (RANGED) {
-                bucket_of[r] = reinterpret_cast<const unsigned char*>(cnt)[static_cast<uint32_t>(r) * THREADS + tid];
-                rb[r] = runs[bucket_of[r]];
+                rb[r] = runs[reinterpret_cast<const unsigned char*>(cnt)[static_cast<uint32_t>(r) * THREADS + tid]];
             } else {
                 rb[r] = runs[dig(okey[r])];
             }
@@ -661,16 +618,7 @@ __global__ __launch_bounds__(THREADS, (INLINE_SCAN ? 3 : reorder_min_waves<Key, 
     RSX_STAMP(6);
     // keys leave first, then the look-ahead counts: both free their registers before the
     // payload takes its own trip through the staging image
-    if (RANGED && to_peers) {
-        if constexpr (RANGED) {
-#pragma unroll
-            for (int r = 0; r < KPT; ++r) {
-                if (full || static_cast<uint32_t>(r) * THREADS + tid < valid) {
-                    reinterpret_cast<Key*>(peer_k[bucket_of[r]])[g[r]] = okey[r];
-                }
-            }
-        }
-    } else if (full) {
+    if (full) {
 #pragma unroll
         for (int r = 0; r < KPT; ++r) {
             out[g[r]] = okey[r];
@@ -725,12 +673,6 @@ __global__ __launch_bounds__(THREADS, (INLINE_SCAN ? 3 : reorder_min_waves<Key, 
         for (int r = 0; r < KPT; ++r) {
             const uint32_t i = static_cast<uint32_t>(r) * THREADS + tid;
             if (full || i < valid) {
-                if constexpr (RANGED) {
-                    if (to_peers) {
-                        reinterpret_cast<uint32_t*>(peer_p[bucket_of[r]])[g[r]] = pay[r];
-                        continue;
-                    }
-                }
                 pout[g[r]] = pay[r];
             }
         }

@@ -288,17 +288,17 @@ int rsxh_plan_from_table(const std::uint64_t* table, int world, int nbuckets, in
     }
 }
 
-int rsxh_plan_choose_splitters(const std::uint64_t* samples, const std::uint32_t* nsamples, const std::uint64_t* shard_sizes, int world, std::uint64_t* out,
+int rsxh_plan_choose_splitters(const std::uint64_t* samples, const std::uint32_t* nsamples, const std::uint64_t* shard_sizes, int nrows, int world, std::uint64_t* out,
                                int* nout)
 {
-    if (!nsamples || !shard_sizes || !out || !nout || world < 1) return -1;
-    std::vector<std::vector<std::uint64_t>> s(static_cast<std::size_t>(world));
+    if (!nsamples || !shard_sizes || !out || !nout || world < 1 || nrows < 0) return -1;
+    std::vector<std::vector<std::uint64_t>> s(static_cast<std::size_t>(nrows));
     std::size_t at = 0;
-    for (int r = 0; r < world; ++r) {
+    for (int r = 0; r < nrows; ++r) {
         s[r].assign(samples + at, samples + at + nsamples[r]);
         at += nsamples[r];
     }
-    const std::vector<std::uint64_t> sp = shardplan::choose_splitters(s, std::vector<std::uint64_t>(shard_sizes, shard_sizes + world), world);
+    const std::vector<std::uint64_t> sp = shardplan::choose_splitters(s, std::vector<std::uint64_t>(shard_sizes, shard_sizes + nrows), world);
     std::copy(sp.begin(), sp.end(), out);
     *nout = static_cast<int>(sp.size());
     return 0;

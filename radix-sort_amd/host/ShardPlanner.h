@@ -75,7 +75,8 @@ int rsxh_plan_wave_layout(const std::uint64_t* table, int world, int nbuckets, i
 int rsxh_plan_balanced_owner(const std::uint64_t* totals, int nbuckets, int world, int* owner);
 int rsxh_plan_from_table(const std::uint64_t* table, int world, int nbuckets, int rank, std::uint64_t* send, std::uint64_t* recv, std::uint64_t* loads,
                          double* imbalance);
-int rsxh_plan_choose_splitters(const std::uint64_t* samples, const std::uint32_t* nsamples, const std::uint64_t* shard_sizes, int world, std::uint64_t* out,
+// nrows sample rows (one per rank that published samples; nsamples[r] values each, concatenated), world - 1 quantiles wanted
+int rsxh_plan_choose_splitters(const std::uint64_t* samples, const std::uint32_t* nsamples, const std::uint64_t* shard_sizes, int nrows, int world, std::uint64_t* out,
                                int* nout);
 int rsxh_plan_split_cuts(const std::uint64_t* totals, int nbuckets, int world, std::uint64_t* cuts);
 int rsxh_plan_split(const std::uint64_t* table, int world, int nbuckets, int rank, std::uint64_t* send, std::uint64_t* recv, std::uint64_t* loads,

@@ -32,7 +32,7 @@ def _load() -> C.CDLL:
         "rsxh_plan_wave_layout": [U64P, I, I, I, U64P, U64P, U64P, U64P],
         "rsxh_plan_balanced_owner": [U64P, I, I, C.POINTER(I)],
         "rsxh_plan_from_table": [U64P, I, I, I, U64P, U64P, U64P, C.POINTER(C.c_double)],
-        "rsxh_plan_choose_splitters": [U64P, C.POINTER(C.c_uint32), U64P, I, U64P, C.POINTER(I)],
+        "rsxh_plan_choose_splitters": [U64P, C.POINTER(C.c_uint32), U64P, I, I, U64P, C.POINTER(I)],
         "rsxh_plan_split_cuts": [U64P, I, I, U64P],
         "rsxh_plan_split": [U64P, I, I, I, U64P, U64P, U64P, C.POINTER(C.c_double)],
         "rsxh_plan_range_buckets": [U64, U64, I, C.POINTER(I), U64P],
@@ -140,12 +140,11 @@ def split_cuts(totals: list[int], world_size: int) -> list[int]:
 
 def choose_splitters(samples: list[list[int]], shard_sizes: list[int], world_size: int) -> list[int]:
     """world_size-1 weighted quantiles of the gathered samples, deduplicated and increasing, at most 7 (unsigned sort order)."""
-    world = len(samples)
-    flat = _arr([v for row in samples for v in row])
-    counts = (C.c_uint32 * max(world, 1))(*[len(row) for row in samples])
-    sizes = list(shard_sizes) + [0] * (world - len(shard_sizes))
+    nrows = min(len(samples), len(shard_sizes))
+    flat = _arr([v for row in samples[:nrows] for v in row])
+    counts = (C.c_uint32 * max(nrows, 1))(*[len(row) for row in samples[:nrows]])
     out, nout = (C.c_uint64 * MAX_SPLITTERS)(), C.c_int(0)
-    if _load().rsxh_plan_choose_splitters(flat, counts, _arr(sizes[:world]), world_size if world == world_size else world, out, C.byref(nout)) != 0:
+    if _load().rsxh_plan_choose_splitters(flat, counts, _arr(shard_sizes[:nrows]), nrows, world_size, out, C.byref(nout)) != 0:
         raise ValueError("choose_splitters: bad arguments")
     return [int(out[i]) for i in range(nout.value)]
 

@@ -35,21 +35,23 @@ class HostStagedDist:
     def destroy_process_group(self):
         td.destroy_process_group()
 
-    def all_reduce(self, t, op=td.ReduceOp.SUM):
+    def all_reduce(self, t, op=td.ReduceOp.SUM, async_op=False):
         h = self._host(t)
         td.all_reduce(h, op=op)
         t.copy_(h)
+        return _Done() if async_op else None
 
     def broadcast(self, t, src=0):
         h = self._host(t)
         td.broadcast(h, src=src)
         t.copy_(h)
 
-    def all_gather_into_tensor(self, out, t):
+    def all_gather_into_tensor(self, out, t, async_op=False):
         h = self._host(t)
         parts = [torch.empty_like(h) for _ in range(td.get_world_size())]
         td.all_gather(parts, h)
         out.copy_(torch.cat([p.reshape(-1) for p in parts]).view(out.shape))
+        return _Done() if async_op else None
 
     def all_to_all_single(self, out, inp, output_split_sizes=None, input_split_sizes=None, async_op=False):
         h_in = self._host(inp)

@@ -115,20 +115,24 @@ class _CpuEngineDouble:
             self._view(d_payload_out, n, np.uint32)[:] = self._view(d_payload, n, np.uint32)[order]
         return [0] + [int(v) for v in np.cumsum(np.bincount(d, minlength=16))]
 
-    def partition_count_waves(self, d_keys, n, world):
+    def msd_count(self, d_keys, n, bits, world, d_counts):
+        """rsx_msd_count: the 2^bits bucket sizes of the top `bits` bits into the caller's row (256 slots, natural order)."""
         u = self._biased(self._view(d_keys, n, self.dtype))
-        b = (u >> u.dtype.type(self.dtype.itemsize * 8 - 4)).astype(np.int64)
-        k = 16 // world
-        self._waves = (d_keys, n, (b % k) * world + b // k)
-        return [int(v) for v in np.bincount(self._waves[2], minlength=16)]
+        kb = self.dtype.itemsize * 8
+        top = (u >> u.dtype.type(kb - 8)).astype(np.int64)
+        sub_shift = 8 - bits
+        c, sub = top >> sub_shift, top & ((1 << sub_shift) - 1)
+        k = (1 << bits) // world
+        self._msd = (d_keys, n, (((c % k) * world + c // k) << sub_shift) | sub)          # wave-major position of every key
+        self._view(d_counts, 256, np.int64)[:] = np.bincount(c, minlength=256)
 
-    def partition_scatter_waves(self, d_keys, n, d_keys_out, d_payload=None, d_payload_out=None):
-        assert self._waves[:2] == (d_keys, n)
+    def msd_scatter(self, d_keys, n, d_staging, d_payload=None, d_staging_payload=None):
+        assert self._msd[:2] == (d_keys, n)
         keys = self._view(d_keys, n, self.dtype)
-        order = np.argsort(self._waves[2], kind="stable")
-        self._view(d_keys_out, n, self.dtype)[:] = keys[order]
+        order = np.argsort(self._msd[2], kind="stable")
+        self._view(d_staging, n, self.dtype)[:] = keys[order]
         if d_payload:
-            self._view(d_payload_out, n, np.uint32)[:] = self._view(d_payload, n, np.uint32)[order]
+            self._view(d_staging_payload, n, np.uint32)[:] = self._view(d_payload, n, np.uint32)[order]
 
     def sort_from_to(self, d_keys, n, first_pass, last_pass, d_keys_out, d_payload=None, d_payload_out=None):
         keys = self._view(d_keys, n, self.dtype).copy()
@@ -195,7 +199,7 @@ def _make_full(kind, dtype, n, orc):
     return orc.dataset(kind, dtype, n, seed=77)
 
 
-def _worker(rank, world, port, dtype, kind, with_payload, n_per_rank, q, strategy="auto"):
+def _worker(rank, world, port, dtype, kind, with_payload, n_per_rank, q, strategy="auto", partition_bits=None):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -217,7 +221,7 @@ def _worker(rank, world, port, dtype, kind, with_payload, n_per_rank, q, strateg
             spay = torch.empty_like(pay)
             rpay = torch.empty(n_per_rank * world, dtype=torch.int32)
         eng = _CpuEngineDouble(dtype)
-        sorter = d.ShardedSorter(eng, rank, world, np.dtype(dtype).itemsize * 8, dist, strategy=strategy)
+        sorter = d.ShardedSorter(eng, rank, world, np.dtype(dtype).itemsize * 8, dist, strategy=strategy, partition_bits=partition_bits)
         out = opay = None
         if strategy in ("auto", "waves"):
             out = torch.empty_like(recv)
@@ -263,14 +267,20 @@ def test_sharded_sort_world4(dtype, kind, with_payload, strategy):
     _run_world(4, dtype, kind, with_payload, strategy)
 
 
-def _run_world(world, dtype, kind, with_payload, strategy):
+@pytest.mark.parametrize("world,dtype,with_payload,bits", [(2, "uint32", True, 1), (2, "int64", False, 6), (2, "uint64", True, 8), (4, "int32", True, 2), (4, "uint32", False, 8)])
+def test_sharded_sort_partition_bits(world, dtype, with_payload, bits):
+    """The pipeline depth is a parameter: 2^bits / world waves per rank, local sorts over the remaining bits only."""
+    _run_world(world, dtype, "SeededUniform", with_payload, "waves", partition_bits=bits)
+
+
+def _run_world(world, dtype, kind, with_payload, strategy, partition_bits=None):
     import torch.multiprocessing as mp
     from _oracle import Oracle
     n_per_rank = 3000
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, dtype, kind, with_payload, n_per_rank, q, strategy)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, dtype, kind, with_payload, n_per_rank, q, strategy, partition_bits)) for r in range(world)]
     for p in procs:
         p.start()
     outs = sorted((q.get(timeout=180) for _ in range(world)), key=lambda t: t[0])
@@ -385,6 +395,67 @@ def test_too_small_receive_buffer_raises_on_every_rank(strategy, short_payload):
     assert all(o[1].startswith("capacity:rank 1 would receive") for o in outs), outs
 
 
+class _FlaggedEngine(_CpuEngineDouble):
+    """The double with rsx_check_status: reports (once) that a fused table scan of an earlier step timed out."""
+
+    def __init__(self, dtype, flagged):
+        super().__init__(dtype)
+        self.flagged = flagged
+
+    def check_status(self):
+        if self.flagged:
+            self.flagged = False
+            raise RuntimeError("rsx_check_status: OperationStatus::CALCULATION_FAILED (a fused table scan timed out)")
+
+
+def _status_worker(rank, world, port, strategy, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        d = _dist_module()
+        from _oracle import Oracle
+        n = 4000
+        kind = "SeededUniform" if strategy != "range" else "Range"
+        full = Oracle().dataset(kind, "uint32", n * world, seed=3)
+        keys = torch.from_numpy(full[rank * n:(rank + 1) * n].copy().view(np.int32))
+        staging, recv, out = torch.empty_like(keys), torch.empty(n * world, dtype=keys.dtype), torch.empty(n * world, dtype=keys.dtype)
+        eng = _FlaggedEngine("uint32", flagged=(rank == 1))          # only rank 1's engine has something to report
+        sorter = d.ShardedSorter(eng, rank, world, 32, dist, strategy=strategy)
+        outcomes = []
+        for _ in range(2):                                           # the second step runs: the flag was reported once and is gone
+            try:
+                sorter.sort(keys, staging, recv, None, None, None, out, None)
+                outcomes.append("sorted")
+            except d.EngineStatusError as exc:
+                outcomes.append("status:" + str(exc))
+            dist.barrier()      # both ranks are still in step
+        q.put((rank, outcomes))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("strategy", ["auto", "waves", "top", "split", "range"])
+def test_engine_status_of_one_rank_raises_on_every_rank(strategy):
+    """One rank's engine reports a timed-out table scan of an earlier step: the flag rides in the row every path gathers anyway, and
+    EVERY rank raises in that step — a lone raise would leave the peers hanging in the next collective."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_status_worker, args=(r, 2, port, strategy, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, outcomes in outs:
+        assert outcomes[0].startswith("status:rank(s) [1] reported an engine error") and outcomes[1] == "sorted", outs
+
+
 def test_sorter_constructor_validates():
     d = _dist_module()
     with pytest.raises(ValueError):
@@ -393,3 +464,7 @@ def test_sorter_constructor_validates():
         d.ShardedSorter(_CpuEngineDouble("uint32"), 2, 2, 32, dist=object())
     with pytest.raises(ValueError):
         d.ShardedSorter(_CpuEngineDouble("uint32"), 0, 1, 32, strategy="nope")
+    with pytest.raises(ValueError):
+        d.ShardedSorter(_CpuEngineDouble("uint32"), 0, 8, 32, dist=object(), partition_bits=2)      # 4 buckets do not feed 8 ranks
+    with pytest.raises(ValueError):
+        d.ShardedSorter(_CpuEngineDouble("uint32"), 0, 2, 32, dist=object(), partition_bits=9)

@@ -837,10 +837,17 @@ def test_count_then_foreign_sort_then_scatter_is_refused(mod, oracle):
         e.sort_from(b.data_ptr(), b.numel())
         with pytest.raises(mod.RadixSortError):
             e.partition_scatter_split(a.data_ptr(), n, out.data_ptr())
-        e.partition_count_waves(a.data_ptr(), n, 4)
+        # rsx_msd_count borrows the 8-BIT tables: a 4-bit sort in between leaves them alone, an 8-bit one voids the count
+        row = torch.zeros(259, dtype=torch.int64, device="cuda")
+        e.msd_count(a.data_ptr(), n, 6, 4, row.data_ptr())
         e.sort_from(b.data_ptr(), b.numel())
+        e.msd_scatter(a.data_ptr(), n, out.data_ptr())
+        e.msd_count(a.data_ptr(), n, 6, 4, row.data_ptr())
+        e.set_option(mod.OPT_RADIX_BITS, 8)
+        e.sort_from(b.data_ptr(), b.numel())
+        e.set_option(mod.OPT_RADIX_BITS, 4)
         with pytest.raises(mod.RadixSortError):
-            e.partition_scatter_waves(a.data_ptr(), n, out.data_ptr())
+            e.msd_scatter(a.data_ptr(), n, out.data_ptr())
         # and the guarded sequence itself still works
         counts = e.partition_count(a.data_ptr(), n, 28, 4)
         e.partition_scatter(a.data_ptr(), n, 28, 4, out.data_ptr())

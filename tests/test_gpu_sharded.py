@@ -76,13 +76,16 @@ class _RankDist:
         work.wait()
         return None
 
-    def all_gather_into_tensor(self, out, t):
+    def all_gather_into_tensor(self, out, t, async_op=False):
         import torch
-        self._collective(t, lambda parts: out.copy_(torch.cat(parts)), False)
+        return self._collective(t, lambda parts: out.copy_(torch.cat(parts)), async_op)
 
-    def all_reduce(self, t, op=None):
-        # used as a stream-ordered barrier only (the peer-store exchange's closing fence): the value is not looked at
-        self._collective(t, lambda parts: None, False)
+    def all_reduce(self, t, op=None, async_op=False):
+        # used as a stream-ordered barrier only (the fence that closes a wave of the peer-store exchange): the value is not looked at
+        return self._collective(t, lambda parts: None, async_op)
+
+    def barrier(self):
+        self.hub.barrier.wait()
 
     def all_to_all_single(self, out, inp, out_splits, in_splits, async_op=False):
         def body(parts):
@@ -115,10 +118,15 @@ def _make_full(kind, dtype, n, oracle):
     ("uint64", "SeededUniform", True, 4, "waves"), ("int32", "SeededUniform", True, 2, "top"), ("uint32", "SeededUniform", False, 3, "auto"),
     # the driver's scaling run is 8 ranks: two pipelined waves; seven splitters when the top bits do not balance
     ("uint32", "SeededUniform", False, 8, "auto"), ("int64", "SeededUniform", True, 8, "auto"), ("uint32", "HeavyTies", True, 8, "auto"),
-    ("uint64", "Skewed", False, 8, "auto"), ("int32", "Range", True, 8, "auto"), ("uint32", "Zeros", True, 8, "auto")])
+    ("uint64", "Skewed", False, 8, "auto"), ("int32", "Range", True, 8, "auto"), ("uint32", "Zeros", True, 8, "auto"),
+    # the pipeline depth is a parameter: 2^bits / world waves per rank ("waves:bits")
+    ("uint32", "SeededUniform", True, 8, "waves:3"), ("uint32", "SeededUniform", False, 8, "waves:4"), ("int64", "SeededUniform", True, 8, "waves:8"),
+    ("uint64", "SeededUniform", True, 2, "waves:1"), ("int32", "SeededUniform", False, 16, "waves:8"), ("uint32", "Random", True, 4, "waves:7")])
 def test_ranks_on_one_gpu(rsx, oracle, dtype, kind, with_payload, world, strategy):
     import torch
     from radix_sort_amd.distributed import ShardedSorter
+    strategy, _, bits = strategy.partition(":")
+    bits = int(bits) if bits else None
     n = 100003
     full = _make_full(kind, dtype, n * world, oracle)
     hub = _Loopback(world)
@@ -141,7 +149,7 @@ def test_ranks_on_one_gpu(rsx, oracle, dtype, kind, with_payload, world, strateg
                 with rsx.Engine(dtype, n * world, payload=with_payload) as eng:
                     if rank % 2 == 0:
                         eng.set_stream(stream.cuda_stream)      # odd ranks leave it to the sorter, which must bind the engine to torch's current stream itself
-                    sorter = ShardedSorter(eng, rank, world, np.dtype(dtype).itemsize * 8, hub.view(rank), strategy=strategy)
+                    sorter = ShardedSorter(eng, rank, world, np.dtype(dtype).itemsize * 8, hub.view(rank), strategy=strategy, partition_bits=bits)
                     obuf = torch.empty_like(recv)
                     opay = torch.empty_like(rpay) if with_payload else None
                     n_local = sorter.sort(keys, staging, recv, pay, spay, rpay, obuf, opay)
@@ -220,37 +228,29 @@ def test_sample_and_split_partition(rsx, oracle, dt):
 
 
 @pytest.mark.parametrize("dt", ["uint32", "int32", "uint64", "int64"])
-@pytest.mark.parametrize("world", [1, 2, 4, 8, 16])
-def test_wave_major_partition_and_partial_sort(rsx, oracle, dt, world):
-    """rsx_partition_count_waves / _scatter_waves / rsx_sort_from_to against numpy."""
+@pytest.mark.parametrize("units_short,radix_bits", [(1, 4), (2, 4), (1, 8), (2, 8)])
+def test_partial_sort_into_caller_buffer(rsx, oracle, dt, units_short, radix_bits):
+    """rsx_sort_from_to against numpy: the passes a wave's local sort needs (all but the top one or two 4-bit units), 4-bit and 8-bit
+    chains, the last pass writing to an odd offset of a caller buffer."""
     import torch
     n = 150001
-    keys = oracle.dataset("SeededUniform", dt, n, seed=world)
+    keys = oracle.dataset("SeededUniform", dt, n, seed=units_short)
     signed = {"uint32": np.int32, "uint64": np.int64}.get(np.dtype(dt).name)
     tk = torch.from_numpy(keys.view(signed) if signed else keys).cuda()
     pay = torch.arange(n, dtype=torch.int32, device="cuda")
-    out, pout = torch.empty_like(tk), torch.empty_like(pay)
     bits = keys.dtype.itemsize * 8
     u = keys.view(np.uint32 if bits == 32 else np.uint64)
     if keys.dtype.kind == "i":
         u = u ^ u.dtype.type(1 << (bits - 1))
-    b = (u >> u.dtype.type(bits - 4)).astype(np.int64)
-    k = 16 // world
-    pos = (b % k) * world + b // k
     with rsx.Engine(dt, n, payload=True) as e:
         e.set_stream(torch.cuda.current_stream().cuda_stream)
-        assert e.partition_count_waves(tk.data_ptr(), n, world) == [int(v) for v in np.bincount(pos, minlength=16)]
-        e.partition_scatter_waves(tk.data_ptr(), n, out.data_ptr(), pay.data_ptr(), pout.data_ptr())
-        torch.cuda.synchronize()
-        order = np.argsort(pos, kind="stable")
-        assert np.array_equal(out.cpu().numpy().view(keys.dtype), keys[order])
-        assert np.array_equal(pout.cpu().numpy().view(np.uint32), order.astype(np.uint32))
-        # sort all passes but the last into an odd offset of a caller buffer
-        passes = bits // 4 - 1
+        if radix_bits != 4:
+            e.set_option(rsx.OPT_RADIX_BITS, radix_bits)
+        units = bits // 4 - units_short
         dst, pdst = torch.zeros(n + 7, dtype=tk.dtype, device="cuda"), torch.zeros(n + 7, dtype=torch.int32, device="cuda")
-        e.sort_from_to(tk.data_ptr(), n, 0, passes, dst[5:].data_ptr(), pay.data_ptr(), pdst[5:].data_ptr())
+        e.sort_from_to(tk.data_ptr(), n, 0, units, dst[5:].data_ptr(), pay.data_ptr(), pdst[5:].data_ptr())
         torch.cuda.synchronize()
-        low = u & u.dtype.type((1 << (4 * passes)) - 1)
+        low = u & u.dtype.type((1 << (4 * units)) - 1)
         order = np.argsort(low, kind="stable")
         got = dst.cpu().numpy().view(keys.dtype)
         assert np.array_equal(got[5:5 + n], keys[order]) and not got[:5].any() and not got[5 + n:].any()
@@ -258,8 +258,6 @@ def test_wave_major_partition_and_partial_sort(rsx, oracle, dt, world):
         # the options of the engine are as before: a plain sort still runs every pass
         e.sort_from(tk.data_ptr(), n, pay.data_ptr())
         assert np.array_equal(e.download(), np.sort(keys))
-        with pytest.raises(rsx.RadixSortError):
-            e.partition_count_waves(tk.data_ptr(), n, 3)
         with pytest.raises(rsx.RadixSortError):
             e.sort_from_to(tk.data_ptr(), n, 3, 3, dst.data_ptr(), pay.data_ptr(), pdst.data_ptr())
 
@@ -299,7 +297,7 @@ def test_bench_through_rccl_single_rank():
     assert line["config"]["verified"].startswith("bit-exact vs a host sort of all 4194304 keys")
     assert "all_to_all" in line["config"]["parallelism"] and "waves" in line["config"]["parallelism"]
     assert line["cpu_baseline"]["value"] > 0 and line["roofline"]["frac"] > 0
-    assert {"count+plan", "scatter", "wait", "local_sort"} <= set(line["sharded_phases_ms"])
+    assert {"count", "scatter", "plan", "wait", "local_sort"} <= set(line["sharded_phases_ms"])
 
 
 @pytest.mark.parametrize("strategy,dtype,payload", [("top", "uint32", False), ("split", "int64", True), ("range", "uint64", False)])
@@ -368,35 +366,6 @@ def test_partition_count_then_scatter(rsx, oracle):
             e.partition_scatter(tk.data_ptr(), n, 28, 4, out.data_ptr())
 
 
-@pytest.mark.parametrize("dt,world", [("uint32", 8), ("int64", 2), ("uint64", 16)])
-def test_wave_counts_left_on_the_device(rsx, oracle, dt, world):
-    """rsx_partition_count_waves_device leaves the same 16 sizes in device memory (no host round trip) and arms the same
-    scatter; n = 0 zeroes the row."""
-    import torch
-    n = 300001
-    keys = oracle.dataset("SeededUniform", dt, n, seed=world)
-    signed = {"uint32": np.int32, "uint64": np.int64}.get(dt)
-    tk = torch.from_numpy(keys.view(signed) if signed else keys).cuda()
-    out = torch.empty_like(tk)
-    row = torch.full((18,), -1, dtype=torch.int64, device="cuda")
-    with rsx.Engine(dt, n) as e:
-        e.set_stream(torch.cuda.current_stream().cuda_stream)
-        want = e.partition_count_waves(tk.data_ptr(), n, world)
-        e.partition_scatter_waves(tk.data_ptr(), n, out.data_ptr())
-        torch.cuda.synchronize()
-        first = out.cpu().numpy().copy()
-        e.partition_count_waves_device(tk.data_ptr(), n, world, row.data_ptr())
-        e.partition_scatter_waves(tk.data_ptr(), n, out.data_ptr())
-        torch.cuda.synchronize()
-        assert row[:16].cpu().tolist() == want and row[16:].cpu().tolist() == [-1, -1]
-        assert np.array_equal(out.cpu().numpy(), first)
-        e.partition_count_waves_device(tk.data_ptr(), 0, world, row.data_ptr())
-        torch.cuda.synchronize()
-        assert row[:16].cpu().tolist() == [0] * 16
-        with pytest.raises(rsx.RadixSortError):
-            e.partition_count_waves_device(tk.data_ptr(), n, 3, row.data_ptr())
-
-
 def test_partition_refuses_a_misaligned_payload_input(rsx, oracle):
     """The partition kernels read keys AND payload 16 bytes per lane: an input payload pointer that is not 16-byte
     aligned is refused by every partition entry point instead of faulting on the device."""
@@ -414,9 +383,10 @@ def test_partition_refuses_a_misaligned_payload_input(rsx, oracle):
         e.partition_count(tk.data_ptr(), n, 28, 4)
         with pytest.raises(rsx.RadixSortError):
             e.partition_scatter(tk.data_ptr(), n, 28, 4, out.data_ptr(), bad, pout.data_ptr())
-        e.partition_count_waves(tk.data_ptr(), n, 4)
+        row = torch.zeros(259, dtype=torch.int64, device="cuda")
+        e.msd_count(tk.data_ptr(), n, 6, 4, row.data_ptr())
         with pytest.raises(rsx.RadixSortError):
-            e.partition_scatter_waves(tk.data_ptr(), n, out.data_ptr(), bad, pout.data_ptr())
+            e.msd_scatter(tk.data_ptr(), n, out.data_ptr(), bad, pout.data_ptr())
         # and the aligned call still works afterwards
         offs = e.partition(tk.data_ptr(), n, 28, 4, out.data_ptr(), pay.data_ptr(), pout.data_ptr())
         torch.cuda.synchronize()
@@ -465,20 +435,23 @@ def _shard(kind, dtype, offset, n, total):
     return out
 
 
-@pytest.mark.parametrize("radix_bits", [4, 8])
-def test_config4_2pow30_uint32_over_eight_ranks_bit_exact(rsx, radix_bits):
+@pytest.mark.parametrize("strategy,partition_bits,radix_bits", [("waves", 4, 4), ("waves", 6, 4), ("waves", 6, 8), ("waves-p2p", 4, 4), ("waves-p2p", 6, 4), ("waves-p2p", 6, 8)])
+def test_config4_2pow30_uint32_over_eight_ranks_bit_exact(rsx, strategy, partition_bits, radix_bits):
     """BASELINE config 4 at its real size and decomposition: 2^30 uint32 `Random` keys as eight contiguous shards of 2^27
     (rank r = draws r*2^27.. of the generator's stream), eight ranks with their own engine, streams and ShardedSorter — as
     eight THREADS of this one process on the box's one GPU (the pool's process guard admits at most 6 processes on a card,
     so eight rank processes cannot run here; four do: test_bench_config4_input_and_size_as_four_rank_processes), collectives
-    = the loopback above with RCCL's stream semantics.  Two pipelined waves per rank; the concatenation of the ranks'
-    outputs must equal a host sort of all 2^30 keys, key for key."""
+    = the loopback above with RCCL's stream semantics.  Both exchanges — all_to_all per wave, and peer stores (one push + fence per
+    wave into the owners' receive buffers, the plan computed on the device) — at pipeline depths 2 (top 4 bits) and 8 (top 6 bits)
+    waves per rank, 4-bit and 8-bit local passes; the concatenation of the ranks' outputs must equal a host sort of all 2^30 keys,
+    key for key."""
     import torch
     from radix_sort_amd.distributed import ShardedSorter
     world, n = 8, 1 << 27
     total = world * n
     hub = _Loopback(world)
     shards, results, errors = [None] * world, [None] * world, []
+    p2p = strategy == "waves-p2p"
 
     def run(rank):
         try:
@@ -487,18 +460,24 @@ def test_config4_2pow30_uint32_over_eight_ranks_bit_exact(rsx, radix_bits):
             with torch.cuda.stream(stream):
                 keys = torch.from_numpy(shards[rank].view(np.int32)).cuda()
                 staging = torch.empty_like(keys)
-                recv = torch.empty(2 * n, dtype=keys.dtype, device="cuda")
-                obuf = torch.empty_like(recv)
+                recv = None if p2p else torch.empty(2 * n, dtype=keys.dtype, device="cuda")
+                obuf = torch.empty(2 * n, dtype=keys.dtype, device="cuda")
                 with rsx.Engine("uint32", 2 * n) as eng:
                     eng.set_stream(stream.cuda_stream)
                     if radix_bits != 4:
                         eng.set_option(rsx.OPT_RADIX_BITS, radix_bits)
-                    sorter = ShardedSorter(eng, rank, world, 32, hub.view(rank))
-                    for _ in range(2):                       # twice: buffers, epochs and count rows are reused
-                        n_local = sorter.sort(keys, staging, recv, None, None, None, obuf, None)
-                    eng.sync()                               # reports a timed-out table scan, if any
-                    assert sorter.result_in_out and sorter.last_path == "waves"
-                    results[rank] = obuf[:n_local].cpu().numpy().view(np.uint32)
+                    sorter = ShardedSorter(eng, rank, world, 32, hub.view(rank), strategy=strategy, partition_bits=partition_bits)
+                    if p2p:
+                        sorter.setup_peer_exchange(2 * n, keys.device)
+                    try:
+                        for _ in range(2):                       # twice: buffers, epochs and count rows are reused
+                            n_local = sorter.sort(keys, staging, recv, None, None, None, obuf, None)
+                        eng.sync()                               # reports a timed-out table scan, if any
+                        assert sorter.result_in_out and sorter.last_path == strategy
+                        results[rank] = obuf[:n_local].cpu().numpy().view(np.uint32)
+                    finally:
+                        if p2p:
+                            sorter.close_peer_exchange()         # (barrier inside: nobody frees a buffer a peer still has mapped)
         except Exception as exc:   # noqa: BLE001 - surface in the main thread
             errors.append(exc)
             hub.barrier.abort()
@@ -536,58 +515,19 @@ def test_bench_config4_input_and_size_as_four_rank_processes(extra):
     assert "contiguous shards of one Random dataset" in line["config"]["workload"]
     if not extra:
         assert "BASELINE config 4's input and size over 4 ranks" in line["config"]["workload"]
-    assert {"count+plan", "scatter", "wait", "local_sort"} <= set(line["sharded_phases_ms"])
+    assert {"count", "scatter", "plan", "wait", "local_sort"} <= set(line["sharded_phases_ms"])
 
 
 # --------------------------------------------------------------------------- peer-store exchange
-@pytest.mark.parametrize("dt,world,with_payload", [("uint32", 8, False), ("int64", 2, True), ("uint64", 16, True), ("int32", 4, False)])
-def test_wave_scatter_straight_to_destination_addresses(rsx, oracle, dt, world, with_payload):
-    """rsx_partition_scatter_waves_peer: bucket p (wave-major position) lands at the p-th of 16 destination addresses —
-    arbitrary places at element alignment, here odd offsets of separately allocated buffers — stable, payload alongside."""
+@pytest.mark.parametrize("dtype,with_payload,world,radix_bits,bits", [("uint32", False, 8, 4, None), ("int64", True, 4, 4, 8), ("uint64", True, 2, 8, 3), ("uint32", True, 16, 4, 4),
+                                                                     ("int32", True, 8, 8, 6), ("uint64", False, 1, 4, 5)])
+def test_peer_store_exchange_thread_ranks(rsx, oracle, dtype, with_payload, world, radix_bits, bits):
+    """strategy="waves-p2p" with ranks as threads of one process (the receive buffers are addressed by their pointers: the planner
+    says "same pointer" for every peer): the plan is computed on the device, one push per wave copies the rank's segments into the
+    owners' receive buffers on a second stream, one all_reduce per wave fences it, the local sorts follow wave by wave; three steps in
+    a row reuse the buffers.  Rank-order concatenation = the stable sort of everything."""
     import torch
-    n = 200003
-    keys = oracle.dataset("SeededUniform", dt, n, seed=world)
-    signed = {"uint32": np.int32, "uint64": np.int64}.get(np.dtype(dt).name)
-    tk = torch.from_numpy(keys.view(signed) if signed else keys).cuda()
-    pay = torch.arange(n, dtype=torch.int32, device="cuda")
-    bits = keys.dtype.itemsize * 8
-    u = keys.view(np.uint32 if bits == 32 else np.uint64)
-    if keys.dtype.kind == "i":
-        u = u ^ u.dtype.type(1 << (bits - 1))
-    b = (u >> u.dtype.type(bits - 4)).astype(np.int64)
-    k = 16 // world
-    pos = (b % k) * world + b // k
-    with rsx.Engine(dt, n, payload=with_payload) as e:
-        e.set_stream(torch.cuda.current_stream().cuda_stream)
-        counts = e.partition_count_waves(tk.data_ptr(), n, world)
-        assert counts == [int(v) for v in np.bincount(pos, minlength=16)]
-        bufs = [torch.full((c + 9,), -7, dtype=tk.dtype, device="cuda") for c in counts]
-        pbufs = [torch.full((c + 9,), -7, dtype=torch.int32, device="cuda") for c in counts]
-        e.partition_scatter_waves_peer(tk.data_ptr(), n, [bufs[p][p % 5 + 1:].data_ptr() for p in range(16)], pay.data_ptr() if with_payload else None,
-                                       [pbufs[p][p % 5 + 1:].data_ptr() for p in range(16)] if with_payload else None)
-        torch.cuda.synchronize()
-        for p in range(16):
-            got = bufs[p].cpu().numpy().view(keys.dtype)
-            lo = p % 5 + 1
-            idx = np.flatnonzero(pos == p)
-            assert np.array_equal(got[lo:lo + counts[p]], keys[idx]), p
-            assert (got[:lo].view(signed or keys.dtype) == -7).all() and (got[lo + counts[p]:].view(signed or keys.dtype) == -7).all()   # nothing outside
-            if with_payload:
-                assert np.array_equal(pbufs[p].cpu().numpy()[lo:lo + counts[p]], idx.astype(np.int32)), p
-        with pytest.raises(rsx.RadixSortError):          # the count was consumed
-            e.partition_scatter_waves_peer(tk.data_ptr(), n, [bufs[p].data_ptr() for p in range(16)], pay.data_ptr() if with_payload else None,
-                                           [pbufs[p].data_ptr() for p in range(16)] if with_payload else None)
-        e.partition_count_waves(tk.data_ptr(), n, world)
-        with pytest.raises(rsx.RadixSortError):          # a null destination
-            e.partition_scatter_waves_peer(tk.data_ptr(), n, [0] * 16, pay.data_ptr() if with_payload else None, [0] * 16 if with_payload else None)
-
-
-@pytest.mark.parametrize("dtype,with_payload,world,radix_bits", [("uint32", False, 8, 4), ("int64", True, 4, 4), ("uint64", True, 2, 8), ("uint32", True, 16, 4)])
-def test_peer_store_exchange_thread_ranks(rsx, oracle, dtype, with_payload, world, radix_bits):
-    """strategy="waves-p2p" with ranks as threads of one process (the receive buffers are addressed by their pointers): the
-    scatter kernels write straight into the owners' receive buffers, one all_reduce closes the exchange, the local sorts
-    follow; three steps in a row reuse the buffers.  Rank-order concatenation = the stable sort of everything."""
-    import torch
+    from radix_sort_amd import planner
     from radix_sort_amd.distributed import ShardedSorter
     n = 150001
     full = oracle.dataset("SeededUniform", dtype, n * world, seed=41)
@@ -602,24 +542,28 @@ def test_peer_store_exchange_thread_ranks(rsx, oracle, dtype, with_payload, worl
             with torch.cuda.stream(stream):
                 keys = torch.from_numpy(shard.view(signed) if signed else shard).cuda()
                 pay = torch.arange(rank * n, (rank + 1) * n, dtype=torch.int32, device="cuda") if with_payload else None
+                staging = torch.empty_like(keys)
+                spay = torch.empty_like(pay) if with_payload else None
                 obuf = torch.empty(2 * n, dtype=keys.dtype, device="cuda")
                 opay = torch.empty(2 * n, dtype=torch.int32, device="cuda") if with_payload else None
                 with rsx.Engine(dtype, 2 * n, payload=with_payload) as eng:
                     eng.set_stream(stream.cuda_stream)
                     if radix_bits != 4:
                         eng.set_option(rsx.OPT_RADIX_BITS, radix_bits)
-                    sorter = ShardedSorter(eng, rank, world, np.dtype(dtype).itemsize * 8, hub.view(rank), strategy="waves-p2p")
+                    sorter = ShardedSorter(eng, rank, world, np.dtype(dtype).itemsize * 8, hub.view(rank), strategy="waves-p2p",
+                                           partition_bits=bits, force_exchange=True)
                     sorter.setup_peer_exchange(2 * n, keys.device, with_payload)
                     try:
+                        assert sorter._peer["access"] == [planner.PEER_SELF if r == rank else planner.PEER_SAME_POINTER for r in range(world)]
+                        sorter.record_timeline = True
                         for _ in range(3):
-                            n_local = sorter.sort(keys, None, None, pay, None, None, obuf, opay)
+                            n_local = sorter.sort(keys, staging, None, pay, spay, None, obuf, opay)
                         eng.sync()
                         assert sorter.result_in_out and sorter.last_path == "waves-p2p"
-                        assert set(sorter.timeline_ms()) <= {"count+plan", "scatter", "fence", "local_sort"}
+                        assert set(sorter.timeline_ms()) <= {"count", "scatter", "plan", "fence", "local_sort"}
                         results[rank] = (obuf[:n_local].cpu().numpy().view(np.dtype(dtype)), opay[:n_local].cpu().numpy().view(np.uint32) if with_payload else None)
                     finally:
-                        hub.barrier.wait()                   # nobody frees a buffer a peer may still be writing into
-                        sorter.close_peer_exchange()
+                        sorter.close_peer_exchange()         # (barrier inside: nobody frees a buffer a peer may still be writing into)
         except Exception as exc:   # noqa: BLE001 - surface in the main thread
             errors.append(exc)
             hub.barrier.abort()
@@ -635,6 +579,48 @@ def test_peer_store_exchange_thread_ranks(rsx, oracle, dtype, with_payload, worl
         assert np.array_equal(np.concatenate([r[1] for r in results]), np.argsort(full, kind="stable").astype(np.uint32))
 
 
+def test_peer_store_capacity_verdict_raises_on_every_rank(rsx, oracle):
+    """One rank's peer-visible receive buffer is too small: the device-side plan carries the verdict, no push writes anything, and EVERY
+    rank raises CapacityError in the same step."""
+    import torch
+    from radix_sort_amd.distributed import CapacityError, ShardedSorter
+    world, n = 4, 60000
+    full = oracle.dataset("SeededUniform", "uint32", n * world, seed=5)
+    hub = _Loopback(world)
+    outcomes, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                keys = torch.from_numpy(full[rank * n:(rank + 1) * n].copy().view(np.int32)).cuda()
+                staging, obuf = torch.empty_like(keys), torch.empty(2 * n, dtype=keys.dtype, device="cuda")
+                with rsx.Engine("uint32", 2 * n) as eng:
+                    eng.set_stream(stream.cuda_stream)
+                    sorter = ShardedSorter(eng, rank, world, 32, hub.view(rank), strategy="waves-p2p")
+                    sorter.setup_peer_exchange(2 * n if rank != 2 else n // 2, keys.device)
+                    try:
+                        try:
+                            sorter.sort(keys, staging, None, None, None, None, obuf, None)
+                            outcomes[rank] = "sorted"
+                        except CapacityError as exc:
+                            outcomes[rank] = str(exc)
+                        torch.cuda.synchronize()
+                    finally:
+                        sorter.close_peer_exchange()
+        except Exception as exc:   # noqa: BLE001
+            errors.append(exc)
+            hub.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert all(o is not None and o.startswith("rank 2 would receive") for o in outcomes), outcomes
+
+
 @pytest.mark.parametrize("ranks,extra", [(2, ["--total-log2-keys", "23"]), (4, ["--total-log2-keys", "24", "--dtype", "uint64", "--payload", "--dataset", "RandomDistributed"])])
 def test_bench_peer_store_exchange_between_rank_processes(ranks, extra):
     """RSX_STRATEGY=waves-p2p with every rank a PROCESS of its own (bench.py's launcher, all ranks on the box's one GPU): the
@@ -644,4 +630,4 @@ def test_bench_peer_store_exchange_between_rank_processes(ranks, extra):
     assert line["n_gpus"] == ranks and line["rehearsal"] is True
     assert line["config"]["verified"].startswith("bit-exact vs a host sort of all")
     assert "[waves-p2p]" in line["config"]["parallelism"] and "peer stores" in line["config"]["parallelism"]
-    assert set(line["sharded_phases_ms"]) - {"note"} <= {"count+plan", "scatter", "fence", "local_sort"}
+    assert set(line["sharded_phases_ms"]) - {"note"} <= {"count", "scatter", "plan", "fence", "local_sort"}

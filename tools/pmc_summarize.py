@@ -10,9 +10,21 @@ streaming read, so it is doubled; WRITE_SIZE is exact for streaming stores.
 """
 import collections
 import csv
+import hashlib
 import json
 import os
 import sys
+
+
+def kernel_source_digest() -> str:
+    """sha256[:16] over the kernel sources (radix-sort_amd/csrc, sorted by name): bench.py prints a committed traffic figure only while
+    this still matches (same function there) — a kernel that changed without a new PMC pass reports traffic null, not a stale number."""
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "radix-sort_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".hpp", ".inc")):
+            h.update(name.encode() + b"\0" + open(os.path.join(csrc, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def per_kernel(path, counter):
@@ -47,6 +59,7 @@ def main():
     doc[workload] = {
         "correction": "FETCH_SIZE x2 (gfx950 wide coalesced reads), KiB -> bytes, WRITE_SIZE exact",
         "reorder_hbm_bytes_per_launch": reorder["hbm_bytes_per_launch"] if reorder else None,
+        "kernel_source_digest": kernel_source_digest(),
         "kernels": kernels,
     }
     json.dump(doc, open(out, "w"), indent=1)
