@@ -40,7 +40,7 @@ void SortDataRadix(std::span<const T> input, std::span<T> output)
 }  // namespace
 
 void writePerformance(std::ostream& stream, const RuntimesGPU& g, const RuntimesCPU& c, std::size_t numberKeys,
-                      const std::string& datasetName, std::string_view datatype, std::size_t keyBytes, double avgTotalGPU_ms)
+                      const std::string& datasetName, std::string_view datatype, std::size_t keyBytes, double avgTotalGPU_ms, int numGPUs)
 {
     // first ten columns: the reference's schema, same order (Performance/performance.csv:1)
     stream << "NumElements,Datatype,Dataset,avgHistogram,avgScan,avgPaste,avgReorder,avgTotalGPU,avgTotalSTLCPU,avgTotalRDXCPU"
@@ -50,7 +50,7 @@ void writePerformance(std::ostream& stream, const RuntimesGPU& g, const Runtimes
     stream << numberKeys << "," << datatype << "," << datasetName << "," << g.timeHisto.avg << "," << g.timeScan.avg << ","
            << g.timePaste.avg << "," << g.timeReorder.avg << "," << g.timeTotal.avg << "," << c.timeSTL.avg << "," << c.timeRadix.avg
            << "," << (avgTotalGPU_ms > 0 ? static_cast<double>(numberKeys) / avgTotalGPU_ms * 1e-3 : 0.0) << "," << scatter_gbs << ","
-           << 100.0 * scatter_gbs / kHbmPeakGBs << ",1" << std::endl;
+           << 100.0 * scatter_gbs / kHbmPeakGBs << "," << numGPUs << std::endl;
 }
 
 template <typename T>
@@ -85,6 +85,36 @@ bool CRadixSortTask<T>::InitResources(hipc::Device Device, hipc::Context Context
     hb.m_hResultFromGPU.resize(mNumberKeysRounded);
 
     const HostSpans<T> spans = MakeHostSpans(hb);
+    if (mOptions.useSharded()) {
+        // the sharded engine behind the same five calls (src/CRadixSortTask.cpp:289-314 drives exactly one engine)
+        if (mOptions.stepwise || mOptions.overlap || mOptions.zero_copy || mOptions.pinned) {
+            std::cerr << "--stepwise / --pinned / --overlap / --zero-copy are single-GPU modes" << std::endl;
+            return false;
+        }
+        int devices = 0;
+        if (rsx_device_count(&devices) != RSX_OK || devices < mOptions.gpus) {
+            std::cerr << "--gpus " << mOptions.gpus << " but " << devices << " HIP device(s) visible" << std::endl;
+            return false;
+        }
+        ShardedSortOptions so;
+        so.devices.clear();
+        for (int r = 0; r < mOptions.numRanks(); ++r) so.devices.push_back(r % mOptions.gpus);
+        so.exchange = mOptions.exchange == "peer-stores" ? ShardedSortOptions::Exchange::PeerStores : ShardedSortOptions::Exchange::AllToAll;
+        so.comm = mOptions.comm == "rccl" ? ShardedSortOptions::Comm::Rccl : mOptions.comm == "loopback" ? ShardedSortOptions::Comm::Loopback : ShardedSortOptions::Comm::Auto;
+        so.partitionBits = mOptions.partition_bits;
+        so.radixBits = mOptions.radix_bits;
+        so.withPermutation = mOptions.with_permutation;
+        so.forceExchange = mOptions.sharded;
+        mMulti = std::make_unique<RadixSortMultiGPU<T>>();
+        const auto status = mMulti->initialize(so, mNumberKeys, spans);
+        if (status != OperationStatus::OK) {
+            std::cerr << "Failed to initialize the sharded Radix Sort: " << to_string(status) << " (" << mMulti->lastError() << ")\n";
+            mMulti.reset();
+            return false;
+        }
+        if (mOptions.verbose) std::cout << "Sharded over " << mMulti->world() << " ranks, communicator: " << mMulti->communicator() << std::endl;
+        return true;
+    }
     mRadixSortGPU.enablePermutation(mOptions.with_permutation);
     mRadixSortGPU.setStepwise(mOptions.stepwise);
     mRadixSortGPU.setRadixBits(mOptions.radix_bits);
@@ -99,6 +129,10 @@ bool CRadixSortTask<T>::InitResources(hipc::Device Device, hipc::Context Context
 template <typename T>
 void CRadixSortTask<T>::ReleaseResources()
 {
+    if (mMulti) {
+        mMulti->release();
+        mMulti.reset();
+    }
     mRadixSortGPU.release();
 }
 
@@ -112,9 +146,18 @@ void CRadixSortTask<T>::ExecuteTask(hipc::Context, hipc::CommandQueue CommandQue
         auto& perm = mHostData.mHostBuffers.h_Permut;       // downloads overwrite it: restore the identity
         std::iota(perm.begin(), perm.end(), 0U);
     }
-    bool ok = mRadixSortGPU.uploadData(CommandQueue) == OperationStatus::OK;
-    ok = ok && mRadixSortGPU.calculate(CommandQueue) == OperationStatus::OK;
-    ok = ok && mRadixSortGPU.downloadData(CommandQueue) == OperationStatus::OK;
+    bool ok;
+    if (mMulti) {
+        ok = mMulti->uploadData() == OperationStatus::OK;
+        ok = ok && mMulti->calculate() == OperationStatus::OK;
+        ok = ok && mMulti->downloadData() == OperationStatus::OK;
+        if (!ok) std::cerr << "sharded GPU sort failed: " << mMulti->lastError() << std::endl;
+        else if (mOptions.verbose) std::cout << "path: " << mMulti->lastPath() << std::endl;
+    } else {
+        ok = mRadixSortGPU.uploadData(CommandQueue) == OperationStatus::OK;
+        ok = ok && mRadixSortGPU.calculate(CommandQueue) == OperationStatus::OK;
+        ok = ok && mRadixSortGPU.downloadData(CommandQueue) == OperationStatus::OK;
+    }
     if (!ok) {
         mExecutionFailed = true;
         std::cerr << "GPU sort failed: " << rsx_last_error() << std::endl;
@@ -183,7 +226,8 @@ void CRadixSortTask<T>::TestPerformance(hipc::CommandQueue CommandQueue, std::si
     }
     mAvgTotalGPUms = timer.GetElapsedMilliseconds() / static_cast<double>(numIterations);
 
-    const RuntimesGPU t = mRadixSortGPU.getRuntimes();
+    const RuntimesGPU t = runtimesGPU();
+    const int numGPUs = mMulti ? mOptions.gpus : 1;
     const std::string datasetName = m_selectedDataset->name();
     const auto datatype = TypeNameString<T>::stdint_name;
     if (mOptions.perf_to_stdout) {
@@ -212,18 +256,18 @@ void CRadixSortTask<T>::TestPerformance(hipc::CommandQueue CommandQueue, std::si
             std::cout << "File " << name.str() << " already exists, not overwriting!" << std::endl;
         } else {
             std::ofstream out(name.str(), std::ofstream::out | std::ofstream::app);
-            writePerformance(out, t, mRuntimesCPU, mNumberKeysRounded, datasetName, datatype, sizeof(T), mAvgTotalGPUms);
+            writePerformance(out, t, mRuntimesCPU, mNumberKeysRounded, datasetName, datatype, sizeof(T), mAvgTotalGPUms, numGPUs);
         }
     }
     if (mOptions.perf_csv_to_stdout) {
-        writePerformance(std::cout, t, mRuntimesCPU, mNumberKeysRounded, datasetName, datatype, sizeof(T), mAvgTotalGPUms);
+        writePerformance(std::cout, t, mRuntimesCPU, mNumberKeysRounded, datasetName, datatype, sizeof(T), mAvgTotalGPUms, numGPUs);
     }
 }
 
 template <typename T>
 void CRadixSortTask<T>::ComputeGPU(hipc::Context Context, hipc::CommandQueue CommandQueue, const LocalWorkSize& lws)
 {
-    if (mNumberKeys != mNumberKeysRounded) {
+    if (mNumberKeys != mNumberKeysRounded && !mMulti) {
         mRadixSortGPU.padGPUData(CommandQueue, sizeof(T) * mNumberKeys);   // before upload, like the reference (:125-130)
     }
     ExecuteTask(Context, CommandQueue, lws);      // warm-up; its download is what ValidateResults checks

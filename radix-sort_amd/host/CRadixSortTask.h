@@ -16,6 +16,7 @@
 #include "HostData.h"
 #include "Parameters.h"
 #include "RadixSortGPU.h"
+#include "RadixSortMultiGPU.h"
 #include "RadixSortOptions.h"
 #include "Statistics.h"
 
@@ -37,7 +38,7 @@ struct RuntimesCPU {
 /// avgReorder, avgTotalGPU, avgTotalSTLCPU, avgTotalRDXCPU; appended: MkeysPerSec (end to end),
 /// scatterGBs, scatterPctOfPeak, nGPU.
 void writePerformance(std::ostream& stream, const RuntimesGPU& runtimesGPU, const RuntimesCPU& runtimesCPU, std::size_t numberKeys,
-                      const std::string& datasetName, std::string_view datatype, std::size_t keyBytes, double avgTotalGPU_ms);
+                      const std::string& datasetName, std::string_view datatype, std::size_t keyBytes, double avgTotalGPU_ms, int numGPUs = 1);
 
 template <typename T>
 class CRadixSortTask : public IComputeTask {
@@ -56,7 +57,7 @@ public:
 
     // -- read-only views for callers that want the numbers without parsing stdout ----------------
     const RuntimesCPU& runtimesCPU() const { return mRuntimesCPU; }
-    RuntimesGPU runtimesGPU() const { return mRadixSortGPU.getRuntimes(); }
+    RuntimesGPU runtimesGPU() const { return mMulti ? mMulti->getRuntimes() : mRadixSortGPU.getRuntimes(); }
     double averageTotalGPUms() const { return mAvgTotalGPUms; }      ///< upload + sort + download, wall clock
 
 protected:
@@ -70,6 +71,7 @@ protected:
     std::shared_ptr<Dataset<DataType>> m_selectedDataset;
     HostDataWithReference<DataType> mHostData;    ///< keys, diagnostics, permutation, GPU result + both referees' outputs
     RadixSortGPU<DataType> mRadixSortGPU;
+    std::unique_ptr<RadixSortMultiGPU<DataType>> mMulti;      ///< --gpus N / --ranks R / --sharded: the sharded engine takes the place of mRadixSortGPU
     RuntimesCPU mRuntimesCPU{};
     std::uint32_t mNumberKeys{0U};                ///< what the caller asked for
     std::uint32_t mNumberKeysRounded{0U};         ///< what is uploaded, sorted and downloaded

@@ -27,6 +27,13 @@ struct RadixSortOptions {
     bool overlap{false};            ///< --overlap: the timed loop keeps two sorts in flight (upload / sort / download on three streams); implies --pinned
     bool zero_copy{false};          ///< --zero-copy: the timed loop sorts straight out of / into mapped host memory; implies --pinned
     int radix_bits{4};              ///< --radix-bits 4|8: digit width of the fused sort (the reference's _NUM_BITS_PER_RADIX is a compile-time 4, src/Parameters.h:25)
+    // -- sharded sort (RadixSortMultiGPU: one rank thread per GPU in this process) -----------------------------------------
+    int gpus{1};                    ///< --gpus N: shard every task over the first N devices (N > 1, or --sharded, selects RadixSortMultiGPU)
+    int ranks{0};                   ///< --ranks R: R rank threads dealt round-robin over the --gpus devices (default: one per GPU); more ranks than GPUs = loopback communicator
+    bool sharded{false};            ///< --sharded: go through the partition + exchange even with one rank (the communicator talks to itself)
+    std::string comm{"auto"};       ///< --comm auto|rccl|loopback
+    std::string exchange{"all-to-all"};   ///< --exchange all-to-all|peer-stores
+    int partition_bits{0};          ///< --partition-bits B: top key bits of the exchange partition (2^B / ranks waves per rank); 0 = default
 
     explicit RadixSortOptions(const std::vector<std::string>& args = {})
         : num_elements(AlgorithmParameters<float>::_NUM_MAX_INPUT_ELEMS)   // default 2^25 (src/RadixSortOptions.h:18)
@@ -48,11 +55,26 @@ struct RadixSortOptions {
             {"--pinned", &RadixSortOptions::pinned},
             {"--overlap", &RadixSortOptions::overlap},
             {"--zero-copy", &RadixSortOptions::zero_copy},
+            {"--sharded", &RadixSortOptions::sharded},
         };
         for (auto it = args.begin(); it != args.end(); ++it) {
             if (*it == "--num-elements") {
                 if (++it == args.end()) throw std::invalid_argument("--num-elements needs a value");
                 num_elements = static_cast<std::size_t>(std::stoull(*it));
+                continue;
+            }
+            if (*it == "--gpus" || *it == "--ranks" || *it == "--partition-bits") {
+                const std::string flag = *it;
+                if (++it == args.end()) throw std::invalid_argument(flag + " needs a value");
+                const int v = std::stoi(*it);
+                if (v < 0 || v > 16) throw std::invalid_argument(flag + " out of range");
+                (flag == "--gpus" ? gpus : flag == "--ranks" ? ranks : partition_bits) = v;
+                continue;
+            }
+            if (*it == "--comm" || *it == "--exchange") {
+                const std::string flag = *it;
+                if (++it == args.end()) throw std::invalid_argument(flag + " needs a value");
+                (flag == "--comm" ? comm : exchange) = *it;
                 continue;
             }
             if (*it == "--radix-bits") {
@@ -66,5 +88,12 @@ struct RadixSortOptions {
             }
         }
         if (overlap || zero_copy) pinned = true;
+        if (gpus < 1) gpus = 1;
+        if (comm != "auto" && comm != "rccl" && comm != "loopback") throw std::invalid_argument("--comm must be auto, rccl or loopback");
+        if (exchange != "all-to-all" && exchange != "peer-stores") throw std::invalid_argument("--exchange must be all-to-all or peer-stores");
     }
+
+    /// More than one rank, or asked for explicitly: the task runs on RadixSortMultiGPU.
+    bool useSharded() const { return sharded || gpus > 1 || ranks > 1; }
+    int numRanks() const { return ranks > 0 ? ranks : gpus; }
 };

@@ -179,9 +179,10 @@ void range_buckets(std::uint64_t lo, std::uint64_t hi, int key_bits, int* shift,
 {
     *shift = 0;
     *mul = 0;
-    const unsigned __int128 span1 = static_cast<unsigned __int128>(hi - lo) + 1;
+    __extension__ typedef unsigned __int128 u128;
+    const u128 span1 = static_cast<u128>(hi - lo) + 1;
     if (span1 <= 16) return;
-    const unsigned __int128 m = (static_cast<unsigned __int128>(16) << key_bits) / span1;
+    const u128 m = (static_cast<u128>(16) << key_bits) / span1;
     *mul = static_cast<std::uint64_t>(m);
 }
 

@@ -9,12 +9,16 @@
 #include "OperationStatus.h"
 #include "Parameters.h"
 #include "RadixSortGPU.h"
+#include "RadixSortMultiGPU.h"
+#include "ShardComm.h"
+#include "ShardPlanner.h"
 #include "RadixSortOptions.h"
 #include "Statistics.h"
 
 #include <algorithm>
 #include <iostream>
 #include <sstream>
+#include <thread>
 
 static int g_failed = 0, g_checked = 0;
 #define CHECK(cond)                                                                  \
@@ -156,6 +160,78 @@ int main()
         CHECK(text.rfind("NumElements,Datatype,Dataset,avgHistogram,avgScan,avgPaste,avgReorder,avgTotalGPU,avgTotalSTLCPU,avgTotalRDXCPU", 0) == 0);
         CHECK(text.find("268435456,uint32_t,Random Random,") != std::string::npos);
         CHECK(std::count(text.begin(), text.begin() + static_cast<std::ptrdiff_t>(text.find('\n')), ',') == 13);
+    }
+
+    // sharded sort, host side: options, the rank threads' rendezvous, the planner the C++ driver calls directly
+    {
+        RadixSortOptions o({"--gpus", "8", "--exchange", "peer-stores", "--partition-bits", "6", "--comm", "loopback"});
+        CHECK(o.useSharded() && o.numRanks() == 8 && o.exchange == "peer-stores" && o.partition_bits == 6 && o.comm == "loopback");
+        RadixSortOptions one({"--ranks", "4"});
+        CHECK(one.useSharded() && one.gpus == 1 && one.numRanks() == 4 && !RadixSortOptions({"--num-elements", "5"}).useSharded());
+        bool threw = false;
+        try {
+            RadixSortOptions bad({"--comm", "carrier-pigeon"});
+        } catch (const std::invalid_argument&) {
+            threw = true;
+        }
+        CHECK(threw);
+
+        const int world = 6;
+        auto hub = std::make_shared<shardcomm::HostHub>(world);
+        std::vector<std::vector<std::uint64_t>> seen(world);
+        std::vector<std::thread> threads;
+        for (int r = 0; r < world; ++r) {
+            threads.emplace_back([&, r] {
+                for (std::uint64_t round = 0; round < 50; ++round) {
+                    const std::vector<std::uint64_t> mine{static_cast<std::uint64_t>(r), round};
+                    const auto all = hub->allGather(r, mine);
+                    for (int s = 0; s < world; ++s) seen[r].push_back(all[s][0] * 1000 + all[s][1]);
+                }
+            });
+        }
+        for (auto& t : threads) t.join();
+        bool same = true;
+        for (int r = 1; r < world; ++r) same = same && seen[r] == seen[0];
+        CHECK(same && seen[0].size() == 50u * world && seen[0][world + 2] == 2 * 1000 + 1);
+        // a rank that fails leaves the rendezvous for good: the others find out and nobody hangs
+        auto hub2 = std::make_shared<shardcomm::HostHub>(3);
+        std::vector<int> outcome(3, -1);
+        std::vector<std::thread> t2;
+        for (int r = 0; r < 3; ++r) {
+            t2.emplace_back([&, r] {
+                if (r == 1) {
+                    hub2->abort("rank 1 gave up");
+                    outcome[r] = 1;
+                    return;
+                }
+                const int v = r;
+                const auto all = hub2->allGather(r, v);
+                outcome[r] = hub2->failed() && all.empty() ? 2 : 3;
+                if (hub2->failed()) hub2->abort("following rank 1");
+            });
+        }
+        for (auto& t : t2) t.join();
+        CHECK(outcome == (std::vector<int>{2, 1, 2}) && hub2->why() == "rank 1 gave up");
+
+        const shardplan::Table table{{5, 0, 7, 1}, {2, 2, 2, 2}};
+        const shardplan::WaveLayout l = shardplan::wave_layout(table, 2, 4, 4);
+        CHECK(l.start[0] == (std::vector<std::uint64_t>{0, 8}) && l.offset[0][0] == (std::vector<std::uint64_t>{0, 5}) && l.load == (std::vector<std::uint64_t>{9, 12}));
+        CHECK(l.start[1] == (std::vector<std::uint64_t>{0, 12}) && l.extent == (std::vector<std::uint64_t>{10, 15}));
+        CHECK(shardplan::check_capacity_extent(l.extent, l.load, {10, 15}, {9, 12}) == -1 && shardplan::check_capacity_extent(l.extent, l.load, {10, 14}, {9, 12}) == 1);
+
+        // without a device the sharded engine refuses like the single one
+        RadixSortMultiGPU<std::uint32_t> multi;
+        CHECK(multi.Resize(1) == 1024 && multi.Resize(1ULL << 32) == (1ULL << 32));
+        int devices = 0;
+        if (rsx_device_count(&devices) != RSX_OK || devices == 0) {
+            std::vector<std::uint32_t> keys(2048, 1U), result(2048), words(2048);
+            HostSpans<std::uint32_t> spans{std::span<std::uint32_t>(keys), std::span<std::uint32_t>(words), std::span<std::uint32_t>(words), std::span<std::uint32_t>(words),
+                                           std::span<std::uint32_t>(result)};
+            ShardedSortOptions so;
+            so.devices = {0, 0};
+            CHECK(multi.initialize(so, 2048, spans) != OperationStatus::OK && !multi.lastError().empty());
+            CHECK(multi.calculate() == OperationStatus::INITIALIZATION_FAILED);
+        }
     }
 
     std::cout << "host_selftest: " << (g_checked - g_failed) << "/" << g_checked << " checks passed" << std::endl;

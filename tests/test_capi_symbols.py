@@ -91,3 +91,22 @@ def test_product_does_not_reference_oracle():
                 if re.search(r"liboracle|oracle/|_oracle|ref_shim|libref_oracle", txt):
                     bad.append(p)
     assert not bad, bad
+
+
+def test_rccl_side_library_exports_what_shardcomm_declares():
+    """libradixsort_rccl.so (RcclComm.hip, hipcc): the five collectives + the error text ShardComm.h declares, linked against librccl.
+    Looked at with nm — it is loaded on demand by RadixSortMultiGPU only, never by a single-GPU run or by the Python binding."""
+    lib = os.path.join(ROOT, "radix-sort_amd", "host", "libradixsort_rccl.so")
+    assert os.path.exists(lib), "run __graft_entry__.build()"
+    header = open(os.path.join(ROOT, "radix-sort_amd", "host", "ShardComm.h")).read()
+    declared = set(re.findall(r"\b(rsxc_rccl_[a-z_]+)\(", header))
+    assert declared == {"rsxc_rccl_create", "rsxc_rccl_destroy", "rsxc_rccl_all_gather", "rsxc_rccl_all_to_all_v", "rsxc_rccl_fence", "rsxc_rccl_last_error"}
+    nm = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in nm.splitlines() if " T " in line}
+    assert declared <= exported
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", lib], capture_output=True, text=True, check=True).stdout
+    for sym in ("ncclCommInitAll", "ncclAllGather", "ncclSend", "ncclRecv", "ncclGroupStart", "ncclGroupEnd", "ncclAllReduce"):
+        assert sym in undefined
+    host = os.path.join(ROOT, "radix-sort_amd", "host", "libradixsort_host.so")
+    needed = subprocess.run(["readelf", "-d", host], capture_output=True, text=True, check=True).stdout
+    assert "librccl" not in needed and "libradixsort_rccl" not in needed        # on demand only

@@ -111,3 +111,47 @@ def test_harness_with_8bit_digits():
     proc = _run([os.path.join(BIN, "rsx_tests"), "--num-elements", str((1 << 18) + 3), "--radix-bits", "8", "--with-permutation", "--perf-csv-to-stdout"])
     assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-2000:]
     assert "20/20 task runs validated" in proc.stdout and "FAILED" not in proc.stdout
+
+
+# --------------------------------------------------------------------------- the sharded engine behind the same harness
+@pytest.mark.parametrize("extra", [
+    ["--ranks", "8", "--num-elements", str((1 << 20) + 5)],                                              # 8 rank threads, loopback, all-to-all per wave
+    ["--ranks", "8", "--num-elements", "300000", "--exchange", "peer-stores", "--with-permutation"],     # peer stores: device-side plan, push + fence per wave
+    ["--ranks", "4", "--num-elements", "200000", "--partition-bits", "8", "--radix-bits", "8", "--with-permutation"],
+    ["--ranks", "2", "--num-elements", "5000", "--partition-bits", "1", "--exchange", "peer-stores"],
+    ["--ranks", "3", "--num-elements", "100000", "--with-permutation"],                                  # not a power of two: splitter path for every dataset
+    ["--sharded", "--comm", "rccl", "--num-elements", "400000", "--with-permutation"],                   # ONE rank through real RCCL (ncclCommInitAll, grouped send/recv to self)
+    ["--sharded", "--comm", "rccl", "--num-elements", "400000", "--exchange", "peer-stores"],            # ... and the ncclAllGather + ncclAllReduce fence of the peer-store path
+])
+def test_sharded_harness_matrix(extra):
+    """`rsx_tests --gpus N` (here: rank THREADS on the box's one GPU, `--ranks R`): RadixSortMultiGPU<T> behind CRadixSortTask's five
+    calls (the reference's seam: src/CRadixSortTask.cpp:289-314, tests/CTestBase.cpp:20-67) — contiguous shards of every dataset,
+    one engine + one communication stream per rank, count -> scatter beside the row exchange -> pipelined exchange -> wave sorts, the
+    splitter path for inputs that do not balance on their top bits (Zeros, Range, InvertedRange), results concatenated in rank order and
+    validated against std::sort AND RadixSortCPU for all 20 (type, dataset) tasks; a failed validation fails the run."""
+    proc = _run([os.path.join(BIN, "rsx_tests"), "-v"] + extra)
+    assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-2000:]
+    assert "20/20 task runs validated" in proc.stdout and "FAILED" not in proc.stdout and "INVALID RESULTS" not in proc.stdout
+    if "--with-permutation" in extra:
+        assert proc.stdout.count("Validation of GPU permutation (stable argsort) has passed") == 20
+    paths = set(re.findall(r"^path: ([a-z0-9-]+)$", proc.stdout, flags=re.M))
+    if "--ranks" in extra and extra[extra.index("--ranks") + 1] == "3":
+        assert paths == {"split"}
+    else:
+        assert ("waves-p2p" if "peer-stores" in extra else "waves") in paths and paths <= {"waves", "waves-p2p", "split", "equal"}
+    if "rccl" in extra:
+        assert "communicator: RCCL" in proc.stdout
+    else:
+        assert "communicator: loopback" in proc.stdout
+
+
+def test_sharded_harness_perf_csv_names_the_gpu_count():
+    proc = _run([os.path.join(BIN, "rsx_tests"), "--ranks", "4", "--num-elements", "65536", "--perf-csv-to-stdout"])
+    assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-2000:]
+    rows = [l for l in proc.stdout.splitlines() if l.startswith("65536,")]
+    assert len(rows) == 20 and all(r.split(",")[-1] == "1" for r in rows)          # four rank threads, ONE GPU
+
+
+def test_sharded_harness_refuses_more_gpus_than_the_box_has():
+    proc = _run([os.path.join(BIN, "rsx_tests"), "--gpus", "16", "--num-elements", "4096"])
+    assert proc.returncode != 0 and "HIP device(s) visible" in proc.stderr
