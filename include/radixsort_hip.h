@@ -301,7 +301,7 @@ int rsx_peer_enable(rsx_engine* e, int peer_device);
  *                    non-zero: its engine reported an error of an earlier step — non-zero on one rank is non-zero on all, and no push writes anything).
  *   rsx_msd_push     wave `wave`: copies this rank's segments of that wave from staging straight into the destinations' receive buffers:
  *                    d_peer_keys / d_peer_payload = DEVICE arrays of `world` base addresses as THIS rank addresses them (rsx_peer_alloc /
- *                    rsx_peer_open / rsx_peer_enable).  `parts` workgroups per destination (<= 0: 16): a link-bound copy that leaves the CUs to
+ *                    rsx_peer_open / rsx_peer_enable).  `parts` workgroups per destination (<= 0: max(16, 128 / world)): a link-bound copy that leaves the CUs to
  *                    the local sorts.  hip_stream (NULL = the engine's): the stream the copy is enqueued on — a second stream lets wave w + 1
  *                    travel while wave w is sorted on the engine's; the call makes it wait for the plan and for rsx_msd_scatter itself.
  *                    The caller fences the wave across ranks (one tiny all_reduce, or its own flags) before sorting it.

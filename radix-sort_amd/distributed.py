@@ -494,25 +494,50 @@ class ShardedSorter:
                 self._plain_table = [[sum(c[b * g:(b + 1) * g]) for b in range(RADIX)] for c in counts]
             self._mark("plan")
             return None
-        # all waves are queued on the collective stream at once; they run in order behind each other (and behind the scatter)
-        pending, send_at = [], 0
+        # The waves are handed to the collective stream from a SIDE stream that waits for the scatter only (a collective orders itself behind
+        # torch's current stream: issued from the engine's stream, wave w + 1 would wait for the local sort of wave w - 1), two waves ahead of
+        # the sorts: the host never stands between the device and its next kernel, the links and the CUs work side by side.
         mine = counts[self.rank]
-        for w in range(k):
+        on_device = getattr(keys, "is_cuda", False)
+        if on_device:
+            import torch
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=keys.device)
+            self._side.wait_stream(torch.cuda.current_stream(keys.device))          # the staging buffer is complete
+        state = {"send_at": 0, "next": 0}
+        pending = []
+
+        def issue():
+            w = state["next"]
+            state["next"] += 1
             send = [mine[d * k + w] for d in range(world)]
             rcv = [counts[s][self.rank * k + w] for s in range(world)]
-            n_send, n_recv = sum(send), sum(rcv)
-            at = start[self.rank][w]
-            works = [self.dist.all_to_all_single(recv[at:at + n_recv], staging[send_at:send_at + n_send], rcv, send, async_op=True)]
-            if payload is not None:
-                works.append(self.dist.all_to_all_single(recv_payload[at:at + n_recv], staging_payload[send_at:send_at + n_send], rcv, send, async_op=True))
+            n_send, n_recv, at, send_at = sum(send), sum(rcv), start[self.rank][w], state["send_at"]
+            state["send_at"] += n_send
+
+            def call():
+                works = [self.dist.all_to_all_single(recv[at:at + n_recv], staging[send_at:send_at + n_send], rcv, send, async_op=True)]
+                if payload is not None:
+                    works.append(self.dist.all_to_all_single(recv_payload[at:at + n_recv], staging_payload[send_at:send_at + n_send], rcv, send, async_op=True))
+                return works
+            if on_device:
+                with torch.cuda.stream(self._side):
+                    works = call()
+            else:
+                works = call()
             pending.append((works, at, n_recv))
-            send_at += n_send
+
+        for _ in range(min(2, k)):
+            issue()
         self._mark("plan")
         done = 0
-        for works, at, n_recv in pending:
+        for w in range(k):
+            works, at, n_recv = pending[w]
             for work in works:
                 if work is not None:
                     work.wait()                          # the engine's stream waits for this wave only
+            if state["next"] < k:
+                issue()
             self._mark("wait")
             if n_recv:
                 self.engine.sort_from_to(
@@ -534,14 +559,19 @@ class ShardedSorter:
         if self._push is None:
             self._push = torch.cuda.Stream(device=keys.device)
         fences = []
-        with torch.cuda.stream(self._push):
-            work.wait()
-            self.engine.msd_plan(table.data_ptr(), ROW_LEN, ROW_CAPS, self.rank, self._push.cuda_stream)
-            for w in range(k):
+
+        def push(w):
+            with torch.cuda.stream(self._push):
                 self.engine.msd_push(w, staging.data_ptr(), peer["keys_dev"].data_ptr(), staging_payload.data_ptr() if payload is not None else None,
                                      peer["pays_dev"].data_ptr() if payload is not None else None, self.push_parts, self._push.cuda_stream)
                 # every rank's push of wave w has finished: what this rank received of it is complete
                 fences.append(self.dist.all_reduce(peer["fence"], async_op=True))
+
+        with torch.cuda.stream(self._push):
+            work.wait()
+            self.engine.msd_plan(table.data_ptr(), ROW_LEN, ROW_CAPS, self.rank, self._push.cuda_stream)
+        for w in range(min(2, k)):                       # two waves ahead of the sorts; the rest are issued between the sorts
+            push(w)
         wave_start, wave_count, loads, verdict = self.engine.msd_plan_wait(k, world)
         self.last_imbalance = max(loads) / max(1.0, sum(loads) / world)
         if verdict:
@@ -555,6 +585,8 @@ class ShardedSorter:
         for w in range(k):
             if fences[w] is not None:
                 fences[w].wait()                         # the engine's stream waits for this wave only
+            if len(fences) < k:
+                push(len(fences))
             self._mark("fence")
             if wave_count[w]:
                 self.engine.sort_from_to(
