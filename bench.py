@@ -281,7 +281,7 @@ def main() -> None:
     if args.radix_bits != 4:
         eng.set_option(rsx.OPT_RADIX_BITS, args.radix_bits)
     sorter = ShardedSorter(eng, rank, world, key_bytes * 8, dist, force_exchange=force_exchange, strategy=os.environ.get("RSX_STRATEGY", "auto"),
-                           partition_bits=args.partition_bits)
+                           partition_bits=args.partition_bits, wave_grouping=os.environ.get("RSX_WAVE_GROUPING", "doubling"))
     if os.environ.get("RSX_PUSH_PARTS"):
         sorter.push_parts = int(os.environ["RSX_PUSH_PARTS"])
     if sharded and sorter.strategy == "waves-p2p":
@@ -419,9 +419,15 @@ def main() -> None:
     passes = key_bytes * 8 // args.radix_bits
     waves = sorter.last_path in ("waves", "waves-p2p")
     if sharded:
-        from radix_sort_amd.distributed import local_pass_units
-        units = local_pass_units(key_bytes * 8, sorter.partition_bits) if waves else key_bytes * 2      # 4-bit pass units of a local sort
-        local_passes = units if args.radix_bits == 4 else units // 2 + units % 2                          # ... = scatter launches (8-bit: whole bytes + a nibble)
+        from radix_sort_amd.distributed import wave_groups, group_pass_units
+        def launches(units):          # scatter launches of a local sort over `units` 4-bit pass units (8-bit digits: whole bytes + a nibble)
+            return units if args.radix_bits == 4 else units // 2 + units % 2
+        if waves:
+            # the waves are sorted in groups (one by one, or doubling {0} {1} {2,3} {4..7}); a group of g of the k waves holds ~ g/k of what arrived
+            k = (1 << sorter.partition_bits) // world
+            local_passes = sum(launches(group_pass_units(key_bytes * 8, sorter.partition_bits, g)) * g / k for _, g in wave_groups(k, sorter.grouping))
+        else:
+            local_passes = launches(key_bytes * 2)
         scatter_bytes_per_step = 2.0 * (key_bytes + pay_bytes) * (n + local_passes * n_local)
         scatter_bytes = scatter_bytes_per_step / launches_per_step if launches_per_step else 0.0
     else:
@@ -448,7 +454,7 @@ def main() -> None:
         "data": "synthetic",
         "config": {"workload": workload, "keys_per_gpu": n, "total_keys": total_keys,
                    "parallelism": "single GPU" if not sharded else (
-                       f"msd-partition[{sorter.last_path}] x{world}" + (f", top {sorter.partition_bits} bits = {(1 << sorter.partition_bits) // world} waves per rank" if waves else "")
+                       f"msd-partition[{sorter.last_path}] x{world}" + (f", top {sorter.partition_bits} bits = {(1 << sorter.partition_bits) // world} waves per rank sorted {'in doubling groups' if sorter.grouping else 'one by one'}" if waves else "")
                        + (" + peer stores into the owners' receive buffers (one push + fence per wave)" if sorter.last_path == "waves-p2p" else " + all_to_all (RCCL)")
                        + " + local LSD sort"),
                    "verified": verified},

@@ -293,8 +293,9 @@ int rsx_peer_enable(rsx_engine* e, int peer_device);
  *                    the all_gather is still in flight.
  *   rsx_msd_plan     from the gathered table d_table[source rank * stride + bucket] (+ every rank's receive and output capacity in keys at
  *                    [.. + cap_at] and [.. + cap_at + 1]) computes ON THE DEVICE, on hip_stream (NULL = the engine's): where each of this
- *                    rank's (wave, destination) segments lands in the destination's receive buffer (waves 16-byte aligned, sources in rank
- *                    order), what this rank receives per wave, every rank's load, and the capacity verdict — then copies the host's part to
+ *                    rank's (wave, destination) segments lands in the destination's receive buffer (sources in rank order; grouping 0: every
+ *                    wave starts 16-byte aligned and is sorted by itself; grouping 1, "doubling groups": only waves 0, 1, 2, 4, 8, ... do, the
+ *                    waves of a group {0} {1} {2,3} {4..7} ... lie gap-free and are sorted together — radix-sort_amd/host/ShardPlanner.h), what this rank receives per wave, every rank's load, and the capacity verdict — then copies the host's part to
  *                    pinned memory.  rsx_msd_plan_wait blocks the HOST until that copy has landed (the device never waits for the host) and
  *                    returns it: wave_start / wave_count (2^bits / world entries, in keys, THIS rank's receive buffer), loads (world entries),
  *                    verdict (0 = go; bit r = rank r's buffers are too small; bit 32 + r = rank r's status word, [.. + cap_at + 2] of its row, was
@@ -310,7 +311,7 @@ int rsx_peer_enable(rsx_engine* e, int peer_device);
  * other's stream so far — engines of one process, any devices). */
 int rsx_msd_count(rsx_engine* e, const void* d_keys, uint64_t n, int bits, int world, uint64_t* d_counts);
 int rsx_msd_scatter(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n, void* d_staging, uint32_t* d_staging_payload);
-int rsx_msd_plan(rsx_engine* e, const uint64_t* d_table, uint32_t stride, uint32_t cap_at, int rank, void* hip_stream);
+int rsx_msd_plan(rsx_engine* e, const uint64_t* d_table, uint32_t stride, uint32_t cap_at, int rank, int grouping, void* hip_stream);
 int rsx_msd_plan_wait(rsx_engine* e, uint64_t* wave_start, uint64_t* wave_count, uint64_t* loads, uint64_t* verdict);
 int rsx_msd_push(rsx_engine* e, int wave, const void* d_staging, const uint32_t* d_staging_payload, const uint64_t* d_peer_keys, const uint64_t* d_peer_payload, int parts,
                  void* hip_stream);

@@ -150,7 +150,7 @@ def load_library() -> C.CDLL:
         "rsx_sort_from_to": ([P, P, P, U64, I, I, P, P], I),
         "rsx_msd_count": ([P, P, U64, I, I, P], I),
         "rsx_msd_scatter": ([P, P, P, U64, P, P], I),
-        "rsx_msd_plan": ([P, P, C.c_uint32, C.c_uint32, I, P], I),
+        "rsx_msd_plan": ([P, P, C.c_uint32, C.c_uint32, I, I, P], I),
         "rsx_msd_plan_wait": ([P, C.POINTER(U64), C.POINTER(U64), C.POINTER(U64), C.POINTER(U64)], I),
         "rsx_msd_push": ([P, I, P, P, P, P, I, P], I),
         "rsx_copy_to_device": ([P, P, P, U64], I),
@@ -418,8 +418,8 @@ class Engine:
         self._check(self.lib.rsx_msd_scatter(self._h, C.c_void_p(d_keys), C.c_void_p(d_payload) if d_payload else None, n, C.c_void_p(d_staging),
                                              C.c_void_p(d_staging_payload) if d_staging_payload else None), "rsx_msd_scatter")
 
-    def msd_plan(self, d_table: int, stride: int, cap_at: int, rank: int, hip_stream: int = 0) -> None:
-        self._check(self.lib.rsx_msd_plan(self._h, C.c_void_p(d_table), stride, cap_at, rank, C.c_void_p(hip_stream) if hip_stream else None), "rsx_msd_plan")
+    def msd_plan(self, d_table: int, stride: int, cap_at: int, rank: int, hip_stream: int = 0, grouping: int = 0) -> None:
+        self._check(self.lib.rsx_msd_plan(self._h, C.c_void_p(d_table), stride, cap_at, rank, grouping, C.c_void_p(hip_stream) if hip_stream else None), "rsx_msd_plan")
 
     def msd_plan_wait(self, waves: int, world: int) -> tuple[list[int], list[int], list[int], int]:
         """(first slot of every wave in this rank's receive buffer, keys of every wave, keys every rank ends up with, verdict bits)"""

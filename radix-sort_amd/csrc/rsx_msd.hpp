@@ -107,7 +107,7 @@ struct MsdPlan {
 // rank's receive / output capacity in keys, [cap_at + 2] = its status word (non-zero: that rank's engine reported an error; everybody stops together).  Receive layout at every destination: the waves follow each other, each starting on a 16-byte
 // boundary (`align` keys: the local sort loads 16 bytes per lane), and inside a wave the sources follow each other in rank order.
 __global__ __launch_bounds__(kRadix8) void msd_layout_kernel(const unsigned long long* __restrict__ table, uint32_t stride, uint32_t cap_at, uint32_t nbuckets,
-                                                             uint32_t world, uint32_t rank, uint32_t align, uint32_t sub_shift,
+                                                             uint32_t world, uint32_t rank, uint32_t align, uint32_t sub_shift, uint32_t grouping,
                                                              const uint32_t* __restrict__ starts, MsdPlan* __restrict__ plan)
 {
     __shared__ unsigned long long bad;
@@ -121,7 +121,9 @@ __global__ __launch_bounds__(kRadix8) void msd_layout_kernel(const unsigned long
         unsigned long long at = 0, total = 0;
         for (uint32_t w = 0; w < waves; ++w) {
             const uint32_t b = dst * waves + w;
-            at = (at + align - 1) / align * align;
+            if (grouping == 0u || (w & (w - 1u)) == 0u) {      // grouping 1 ("doubling groups"): only waves 0, 1, 2, 4, 8, ... start aligned (ShardPlanner.h)
+                at = (at + align - 1) / align * align;
+            }
             const unsigned long long wave_at = at;
             unsigned long long mine_at = 0, wave_total = 0;
             for (uint32_t src = 0; src < world; ++src) {

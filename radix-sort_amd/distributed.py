@@ -20,9 +20,11 @@ radix-sort_amd/host/ShardPlanner.cpp through planner.py — the same code the C+
                place in its destination ON THE DEVICE from the gathered table (no host round trip in front of the data), and one
                `rsx_msd_push` per wave copies this rank's segments straight into the owners' buffers over xGMI on a second
                stream, each wave closed by a one-word all_reduce (its fence)
-      sort     wave w is sorted — all its keys at a rank share the top B bits, so ceil((keybits - B) / 4) pass units suffice
-               (`rsx_sort_from_to`), straight into its place in the output — as soon as wave w has landed, while wave w+1 is
-               on the links.  More bits = more, smaller waves = a smaller exposed first wave.
+      sort     the waves are sorted in DOUBLING GROUPS {0} {1} {2,3} {4..7} ...: wave 0 as soon as it has landed (the exposed part
+               of the exchange is 1/k of it), the later groups — gap-free in the receive buffer — together, at the big-sort rate, while
+               the next group is on the links.  A group of 2^j aligned buckets shares the top B - j bits, so its sort
+               (`rsx_sort_from_to`, straight into its place in the output) needs ceil((keybits - B + j) / 4) pass units: at B = 6 up
+               to four buckets cost no more than one.  (`wave_grouping="single"` sorts every wave by itself.)
 
   2. Plain top-bit path (other world sizes, no output buffer, or strategy="top"): 16 buckets on the top nibble in key order
   (`rsx_partition_count` / `rsx_partition_scatter`), dealt to the ranks as contiguous ranges balanced on the global counts,
@@ -49,8 +51,9 @@ production); tests inject a CPU test double through the same methods so the spli
 """
 from __future__ import annotations
 
-from .planner import (MAX_SPLITTERS, PEER_ENABLE_THEN_POINTER, PEER_OPEN_IPC, CapacityError, ExchangePlan, balanced_owner,  # noqa: F401  (re-exported)
-                      check_capacity, choose_splitters, peer_access, plan_from_table, range_buckets, split_cuts, split_plan, wave_extents, wave_layout)
+from .planner import (GROUP_DOUBLING, GROUP_SINGLE, MAX_SPLITTERS, PEER_ENABLE_THEN_POINTER, PEER_OPEN_IPC, CapacityError, ExchangePlan,  # noqa: F401  (re-exported)
+                      balanced_owner, check_capacity, choose_splitters, group_pass_units, peer_access, plan_from_table, range_buckets, split_cuts, split_plan,
+                      wave_extents, wave_groups, wave_layout)
 
 RADIX = 16                  # buckets of the one-shot paths (top / split / range): the 16-bucket partition kernels
 TOP_BITS = 4
@@ -205,7 +208,7 @@ class ShardedSorter:
     STRATEGIES = ("auto", "waves", "waves-p2p", "split", "range", "top")
 
     def __init__(self, engine, rank: int, world_size: int, key_bits: int, dist=None, force_exchange: bool = False, strategy: str = "auto",
-                 partition_bits: int | None = None):
+                 partition_bits: int | None = None, wave_grouping: str = "doubling"):
         if world_size > 1 and dist is None:
             raise ValueError("a torch.distributed module (or a stand-in with its calls) is required for world_size > 1")
         if not 0 <= rank < world_size:
@@ -229,6 +232,9 @@ class ShardedSorter:
         if self.can_wave and not (1 <= bits <= 8 and (1 << bits) >= world_size):
             raise ValueError(f"partition_bits must be in 1..8 with 2^bits >= the world size, got {bits}")
         self.partition_bits = bits
+        if wave_grouping not in ("doubling", "single"):
+            raise ValueError(f"wave_grouping must be 'doubling' or 'single', got {wave_grouping!r}")
+        self.grouping = GROUP_DOUBLING if wave_grouping == "doubling" else GROUP_SINGLE
         self.push_parts = 0            # workgroups per destination of a wave's push (0: the library's default)
         self.last_path = None          # "local" | "waves" | "waves-p2p" | "top" | "split" | "range" | "equal" (for tests and logs)
         self.last_imbalance = None
@@ -463,7 +469,7 @@ class ShardedSorter:
         nb = 1 << bits
         k = nb // world
         itemsize = self.key_bits // 8
-        units = local_pass_units(self.key_bits, bits)
+        groups = wave_groups(k, self.grouping) if self.can_wave else []
         row, table = self._rows(keys.device)
         self.engine.msd_count(keys.data_ptr(), n, bits, world, row.data_ptr())
         self._mark("count")
@@ -473,12 +479,12 @@ class ShardedSorter:
         self.engine.msd_scatter(keys.data_ptr(), n, staging.data_ptr(), pay_in, pay_st)          # needs only this rank's counts: runs beside the all_gather
         self._mark("scatter")
         if p2p:
-            return self._finish_waves_p2p(work, table, keys, staging, staging_payload, payload, out, out_payload, k, units, itemsize)
+            return self._finish_waves_p2p(work, table, keys, staging, staging_payload, payload, out, out_payload, k, groups, itemsize)
         rows = self._table_to_host(work, table)
         _raise_together([r[ROW_STATUS] for r in rows])
         counts = [r[:nb] for r in rows]
         caps = [(r[ROW_CAPS], r[ROW_CAPS + 1]) for r in rows]
-        start, _, loads = wave_layout(counts, world, nb)
+        start, _, loads = wave_layout(counts, world, nb, 4, self.grouping)
         imbalance = max(loads) / max(1.0, sum(loads) / world)
         fits = True
         try:
@@ -527,29 +533,35 @@ class ShardedSorter:
                 works = call()
             pending.append((works, at, n_recv))
 
-        for _ in range(min(2, k)):
+        # the next group's waves are issued before this group's sort is enqueued
+        while state["next"] < groups[0][0] + groups[0][1]:
             issue()
         self._mark("plan")
         done = 0
-        for w in range(k):
-            works, at, n_recv = pending[w]
-            for work in works:
-                if work is not None:
-                    work.wait()                          # the engine's stream waits for this wave only
-            if state["next"] < k:
-                issue()
+        for g, (first, nwaves) in enumerate(groups):
+            if g + 1 < len(groups):
+                while state["next"] < groups[g + 1][0] + groups[g + 1][1]:
+                    issue()
+            n_group = 0
+            for w in range(first, first + nwaves):
+                works, _, n_recv = pending[w]
+                for work in works:
+                    if work is not None:
+                        work.wait()                      # the engine's stream waits for the waves of this group only
+                n_group += n_recv
             self._mark("wait")
-            if n_recv:
+            if n_group:
+                at = pending[first][1]
                 self.engine.sort_from_to(
-                    recv[at:].data_ptr(), n_recv, 0, units, out[done:].data_ptr(),
+                    recv[at:].data_ptr(), n_group, 0, group_pass_units(self.key_bits, bits, nwaves), out[done:].data_ptr(),
                     recv_payload[at:].data_ptr() if payload is not None else None,
                     out_payload[done:].data_ptr() if payload is not None else None)
             self._mark("local_sort")
-            done += n_recv
+            done += n_group
         self.last_path, self.last_imbalance, self.result_in_out = "waves", imbalance, True
         return done
 
-    def _finish_waves_p2p(self, work, table, keys, staging, staging_payload, payload, out, out_payload, k, units, itemsize):
+    def _finish_waves_p2p(self, work, table, keys, staging, staging_payload, payload, out, out_payload, k, groups, itemsize):
         """The exchange by peer stores: plan on the device, one push + fence per wave on a second stream, the local sort of wave w on
         the engine's stream as soon as its fence has passed.  The host blocks once, for the plan's copy (its own wave sizes: the sort
         launches need them), while the pushes are already queued."""
@@ -569,8 +581,8 @@ class ShardedSorter:
 
         with torch.cuda.stream(self._push):
             work.wait()
-            self.engine.msd_plan(table.data_ptr(), ROW_LEN, ROW_CAPS, self.rank, self._push.cuda_stream)
-        for w in range(min(2, k)):                       # two waves ahead of the sorts; the rest are issued between the sorts
+            self.engine.msd_plan(table.data_ptr(), ROW_LEN, ROW_CAPS, self.rank, self._push.cuda_stream, self.grouping)
+        for w in range(groups[0][0] + groups[0][1]):      # the first group now; every later group before the sort of the one in front of it
             push(w)
         wave_start, wave_count, loads, verdict = self.engine.msd_plan_wait(k, world)
         self.last_imbalance = max(loads) / max(1.0, sum(loads) / world)
@@ -582,19 +594,24 @@ class ShardedSorter:
         self._mark("plan")
         mine_k, mine_p = peer["mine"]
         done = 0
-        for w in range(k):
-            if fences[w] is not None:
-                fences[w].wait()                         # the engine's stream waits for this wave only
-            if len(fences) < k:
-                push(len(fences))
+        bits = self.partition_bits
+        for g, (first, nwaves) in enumerate(groups):
+            if g + 1 < len(groups):
+                for w in range(len(fences), groups[g + 1][0] + groups[g + 1][1]):
+                    push(w)
+            for w in range(first, first + nwaves):
+                if fences[w] is not None:
+                    fences[w].wait()                     # the engine's stream waits for the waves of this group only
             self._mark("fence")
-            if wave_count[w]:
+            n_group = sum(wave_count[first:first + nwaves])
+            if n_group:
+                at = wave_start[first]
                 self.engine.sort_from_to(
-                    mine_k + wave_start[w] * itemsize, wave_count[w], 0, units, out[done:].data_ptr(),
-                    mine_p + wave_start[w] * 4 if payload is not None else None,
+                    mine_k + at * itemsize, n_group, 0, group_pass_units(self.key_bits, bits, nwaves), out[done:].data_ptr(),
+                    mine_p + at * 4 if payload is not None else None,
                     out_payload[done:].data_ptr() if payload is not None else None)
             self._mark("local_sort")
-            done += wave_count[w]
+            done += n_group
         self.last_path, self.result_in_out = "waves-p2p", True
         return done
 

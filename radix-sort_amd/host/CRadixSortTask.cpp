@@ -105,6 +105,7 @@ bool CRadixSortTask<T>::InitResources(hipc::Device Device, hipc::Context Context
         so.radixBits = mOptions.radix_bits;
         so.withPermutation = mOptions.with_permutation;
         so.forceExchange = mOptions.sharded;
+        so.doublingGroups = !mOptions.single_waves;
         mMulti = std::make_unique<RadixSortMultiGPU<T>>();
         const auto status = mMulti->initialize(so, mNumberKeys, spans);
         if (status != OperationStatus::OK) {

@@ -240,7 +240,7 @@ OperationStatus RadixSortMultiGPU<T>::initialize(const ShardedSortOptions& optio
         mLastError = "partitionBits must be in 1..8 with 2^bits >= the number of ranks";
         return S::INITIALIZATION_FAILED;
     }
-    mUnits = (static_cast<int>(sizeof(T)) * 8 - mBits + 3) / 4;      // 4-bit pass units of a wave's local sort: its keys share the top mBits bits
+    mGrouping = mOpt.doublingGroups ? 1 : 0;
     const std::set<int> distinct(options.devices.begin(), options.devices.end());
     const bool oneEach = static_cast<int>(distinct.size()) == mWorld;
     mUseRccl = options.comm == ShardedSortOptions::Comm::Rccl || (options.comm == ShardedSortOptions::Comm::Auto && oneEach && mWorld > 1);
@@ -450,11 +450,12 @@ int RadixSortMultiGPU<T>::stepRank(Rank& r)
 }
 
 template <typename T>
-int RadixSortMultiGPU<T>::sortWave(Rank& r, std::uint64_t start, std::uint64_t count, std::uint64_t done)
+int RadixSortMultiGPU<T>::sortWaves(Rank& r, std::uint64_t start, std::uint64_t count, std::uint64_t done, int groupWaves)
 {
     if (count == 0) return RSX_OK;
     const bool pay = mOpt.withPermutation;
-    return rsx_sort_from_to(r.E, static_cast<const char*>(r.recv) + start * sizeof(T), pay ? r.rpay + start : nullptr, count, 0, mUnits,
+    const int units = shardplan::group_pass_units(static_cast<int>(sizeof(T)) * 8, mBits, groupWaves);      // the group's keys share the top mBits - log2(groupWaves) bits
+    return rsx_sort_from_to(r.E, static_cast<const char*>(r.recv) + start * sizeof(T), pay ? r.rpay + start : nullptr, count, 0, units,
                             static_cast<char*>(r.out) + done * sizeof(T), pay ? r.opay + done : nullptr);
 }
 
@@ -497,22 +498,28 @@ int RadixSortMultiGPU<T>::pipelinedAllToAll(Rank& r, std::uint64_t)
         anyStatus = anyStatus || row[kCapsAt + 2] != 0;
     }
     if (anyStatus) return fail(r, RSX_CALCULATION_FAILED, "a rank's engine reported an error of an earlier step (a table scan that timed out): every rank stops together");
-    const shardplan::WaveLayout layout = shardplan::wave_layout(counts, mWorld, nb, 4);
+    const shardplan::WaveLayout layout = shardplan::wave_layout(counts, mWorld, nb, 4, mGrouping);
     const std::uint64_t total = std::accumulate(layout.load.begin(), layout.load.end(), std::uint64_t{0});
     const double imbalance = static_cast<double>(*std::max_element(layout.load.begin(), layout.load.end())) / std::max(1.0, static_cast<double>(total) / mWorld);
     const bool fits = shardplan::check_capacity_extent(layout.extent, layout.load, recvCaps, outCaps) < 0;
     if (!fits || imbalance > mOpt.maxImbalance) return -1;      // same verdict on every rank: it only depends on the gathered table
-    // wave w + 1 is handed to the communicator before wave w's sort is enqueued: the links and the CUs work side by side
+    // the next group's waves are handed to the communicator before this group's sort is enqueued: the links and the CUs work side by side
+    const auto groups = shardplan::wave_groups(k, mGrouping);
     std::uint64_t sendAt = 0, done = 0;
+    int issued = 0;
     RSX_STEP(rsx_wait_for(r.C, r.E), "rsx_wait_for");                                   // the staging buffer is complete
-    RSX_STEP(exchangeWave(r, 0, counts, layout, sendAt), "exchange of wave 0");
-    for (int w = 0; w < k; ++w) {
-        RSX_STEP(rsx_wait_for(r.E, r.C), "rsx_wait_for");                               // waves 0..w have landed
-        if (w + 1 < k) RSX_STEP(exchangeWave(r, w + 1, counts, layout, sendAt), "exchange of a wave");
-        const std::uint64_t cnt = std::accumulate(counts.begin(), counts.end(), std::uint64_t{0}, [&](std::uint64_t a, const std::vector<std::uint64_t>& row) {
-            return a + row[static_cast<std::size_t>(r.rank * k + w)];
-        });
-        RSX_STEP(sortWave(r, layout.start[static_cast<std::size_t>(r.rank)][static_cast<std::size_t>(w)], cnt, done), "local sort of a wave");
+    for (; issued < groups[0].first + groups[0].second; ++issued) RSX_STEP(exchangeWave(r, issued, counts, layout, sendAt), "exchange of a wave");
+    for (std::size_t g = 0; g < groups.size(); ++g) {
+        const int first = groups[g].first, waves = groups[g].second;
+        RSX_STEP(rsx_wait_for(r.E, r.C), "rsx_wait_for");                               // every wave of this group has landed
+        if (g + 1 < groups.size()) {
+            for (; issued < groups[g + 1].first + groups[g + 1].second; ++issued) RSX_STEP(exchangeWave(r, issued, counts, layout, sendAt), "exchange of a wave");
+        }
+        std::uint64_t cnt = 0;
+        for (int w = first; w < first + waves; ++w) {
+            for (const auto& row : counts) cnt += row[static_cast<std::size_t>(r.rank * k + w)];
+        }
+        RSX_STEP(sortWaves(r, layout.start[static_cast<std::size_t>(r.rank)][static_cast<std::size_t>(first)], cnt, done, waves), "local sort of a group of waves");
         done += cnt;
     }
     r.nOut = done;
@@ -528,13 +535,15 @@ int RadixSortMultiGPU<T>::pipelinedPeerStores(Rank& r)
     // (the all_gather is also the step's opening barrier: nobody pushes into a receive buffer whose owner still sorts out of it)
     RSX_STEP(r.comm->allGather(r.d_row, r.d_table, sizeof(Row)), "all_gather of the count rows");
     RSX_STEP(rsx_msd_scatter(r.E, r.keys, r.pay, r.n, r.staging, r.spay), "rsx_msd_scatter");
-    RSX_STEP(rsx_msd_plan(r.E, r.d_table, kRowLen, kCapsAt, r.rank, r.cstream), "rsx_msd_plan");
+    RSX_STEP(rsx_msd_plan(r.E, r.d_table, kRowLen, kCapsAt, r.rank, mGrouping, r.cstream), "rsx_msd_plan");
     auto push = [&](int w) {
         int rc = rsx_msd_push(r.E, w, r.staging, pay ? r.spay : nullptr, r.d_peerKeys, pay ? r.d_peerPays : nullptr, mOpt.pushParts, r.cstream);
         if (rc == RSX_OK) rc = r.comm->fence();          // every rank's push of this wave has finished
         return rc;
     };
-    RSX_STEP(push(0), "push of wave 0");
+    const auto groups = shardplan::wave_groups(k, mGrouping);
+    int issued = 0;
+    for (; issued < groups[0].first + groups[0].second; ++issued) RSX_STEP(push(issued), "push of a wave");
     std::vector<std::uint64_t> start(static_cast<std::size_t>(k)), count(start.size()), loads(static_cast<std::size_t>(mWorld));
     std::uint64_t verdict = 0;
     RSX_STEP(rsx_msd_plan_wait(r.E, start.data(), count.data(), loads.data(), &verdict), "rsx_msd_plan_wait");      // the host's one wait: its own wave sizes
@@ -543,14 +552,18 @@ int RadixSortMultiGPU<T>::pipelinedPeerStores(Rank& r)
     const std::uint64_t total = std::accumulate(loads.begin(), loads.end(), std::uint64_t{0});
     const double imbalance = static_cast<double>(*std::max_element(loads.begin(), loads.end())) / std::max(1.0, static_cast<double>(total) / mWorld);
     // the fixed bucket ownership overflows somebody's buffers or leaves the ranks uneven (keys that do not use their top bits): the general path takes over.
-    // (Wave 0 may already have been pushed — into receive buffers the general path overwrites later on the same communication streams.)
+    // (The first wave may already have been pushed — into receive buffers the general path overwrites later on the same communication streams.)
     if (verdict || imbalance > mOpt.maxImbalance) return -1;
     std::uint64_t done = 0;
-    for (int w = 0; w < k; ++w) {
-        RSX_STEP(rsx_wait_for(r.E, r.C), "rsx_wait_for");            // waves 0..w have landed here
-        if (w + 1 < k) RSX_STEP(push(w + 1), "push of a wave");
-        const std::uint64_t at = start[static_cast<std::size_t>(w)], cnt = count[static_cast<std::size_t>(w)];
-        RSX_STEP(sortWave(r, at, cnt, done), "local sort of a wave");
+    for (std::size_t g = 0; g < groups.size(); ++g) {
+        const int first = groups[g].first, waves = groups[g].second;
+        RSX_STEP(rsx_wait_for(r.E, r.C), "rsx_wait_for");            // every wave of this group has landed here
+        if (g + 1 < groups.size()) {
+            for (; issued < groups[g + 1].first + groups[g + 1].second; ++issued) RSX_STEP(push(issued), "push of a wave");
+        }
+        std::uint64_t cnt = 0;
+        for (int w = first; w < first + waves; ++w) cnt += count[static_cast<std::size_t>(w)];
+        RSX_STEP(sortWaves(r, start[static_cast<std::size_t>(first)], cnt, done, waves), "local sort of a group of waves");
         done += cnt;
     }
     r.nOut = done;

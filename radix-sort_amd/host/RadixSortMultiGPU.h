@@ -13,7 +13,8 @@
 //                        memory; wave_layout; one grouped send/recv per wave on the communication stream
 //            PeerStores: device all_gather of the rows, rsx_msd_plan on the device, one rsx_msd_push + fence per wave into the other
 //                        ranks' receive buffers (same process: their pointers, after rsx_peer_enable for another device)
-//   sort     wave w as soon as it has landed (rsx_wait_for on the communication stream), while wave w + 1 travels
+//   sort     the waves in doubling groups {0} {1} {2,3} {4..7}: wave 0 as soon as it has landed (rsx_wait_for on the communication stream), the
+//            later, larger groups at the big-sort rate while the next group travels; up to 4 buckets cost no extra pass unit at B = 6
 // Inputs that do not balance on their top bits take the splitter path (samples -> quantile splitters -> tie-splitting cut plan,
 // one all-to-all, full local sort), up to 8 ranks.  Rank-order concatenation of the ranks' outputs is the sorted array
 // (with `withPermutation`: the stable argsort), which downloadData assembles in m_hResultFromGPU.
@@ -47,6 +48,7 @@ struct ShardedSortOptions {
     bool forceExchange{false};          ///< one rank: still partition and exchange (the communicator talks to itself)
     double maxImbalance{1.25};          ///< the fixed bucket ownership is used while no rank gets more than this x its share
     int pushParts{0};                   ///< workgroups per destination of a wave's push (0: the library's default)
+    bool doublingGroups{true};          ///< the local sorts take the waves in groups {0} {1} {2,3} {4..7} ... (ShardPlanner.h) instead of one by one
 };
 
 template <typename DataType>
@@ -104,7 +106,7 @@ private:
     int pipelinedPeerStores(Rank& r);
     int splitterPath(Rank& r, std::uint64_t status);
     int exchangeWave(Rank& r, int wave, const shardplan::Table& counts, const shardplan::WaveLayout& layout, std::uint64_t& sendAt);
-    int sortWave(Rank& r, std::uint64_t start, std::uint64_t count, std::uint64_t done);
+    int sortWaves(Rank& r, std::uint64_t start, std::uint64_t count, std::uint64_t done, int groupWaves);
     int fail(Rank& r, int rc, const std::string& what);
 
     ShardedSortOptions mOpt{};
@@ -112,7 +114,7 @@ private:
     std::vector<Rank> mRanks;
     std::shared_ptr<shardcomm::HostHub> mHub;
     std::uint64_t mTotal{0};
-    int mWorld{0}, mBits{0}, mUnits{0};
+    int mWorld{0}, mBits{0}, mGrouping{1};
     bool mCanWave{false}, mUseRccl{false};
     RuntimesGPU mRuntimes{};
     std::string mLastPath, mLastError;

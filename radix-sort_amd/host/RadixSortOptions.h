@@ -34,6 +34,7 @@ struct RadixSortOptions {
     std::string comm{"auto"};       ///< --comm auto|rccl|loopback
     std::string exchange{"all-to-all"};   ///< --exchange all-to-all|peer-stores
     int partition_bits{0};          ///< --partition-bits B: top key bits of the exchange partition (2^B / ranks waves per rank); 0 = default
+    bool single_waves{false};       ///< --single-waves: sort every wave by itself instead of in doubling groups {0} {1} {2,3} {4..7}
 
     explicit RadixSortOptions(const std::vector<std::string>& args = {})
         : num_elements(AlgorithmParameters<float>::_NUM_MAX_INPUT_ELEMS)   // default 2^25 (src/RadixSortOptions.h:18)
@@ -56,6 +57,7 @@ struct RadixSortOptions {
             {"--overlap", &RadixSortOptions::overlap},
             {"--zero-copy", &RadixSortOptions::zero_copy},
             {"--sharded", &RadixSortOptions::sharded},
+            {"--single-waves", &RadixSortOptions::single_waves},
         };
         for (auto it = args.begin(); it != args.end(); ++it) {
             if (*it == "--num-elements") {

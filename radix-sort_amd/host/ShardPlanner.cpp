@@ -13,7 +13,25 @@ std::uint64_t ExchangePlan::n_recv() const
     return std::accumulate(recv.begin(), recv.end(), std::uint64_t{0});
 }
 
-WaveLayout wave_layout(const Table& table, int world, int nbuckets, int align)
+std::vector<std::pair<int, int>> wave_groups(int waves, int grouping)
+{
+    std::vector<std::pair<int, int>> out;
+    if (grouping == 0) {
+        for (int w = 0; w < waves; ++w) out.emplace_back(w, 1);
+    } else {
+        for (int w = 0, g = 1; w < waves; w += g, g = (w <= 1 ? 1 : w)) out.emplace_back(w, std::min(g, waves - w));      // {0} {1} {2,3} {4..7} ...
+    }
+    return out;
+}
+
+int group_pass_units(int key_bits, int partition_bits, int group_waves)
+{
+    int lg = 0;
+    while ((1 << lg) < group_waves) ++lg;
+    return (key_bits - (partition_bits - lg) + 3) / 4;
+}
+
+WaveLayout wave_layout(const Table& table, int world, int nbuckets, int align, int grouping)
 {
     if (world < 1 || nbuckets < world || nbuckets % world != 0 || static_cast<int>(table.size()) != world || align < 1)
         throw std::invalid_argument("wave_layout: the table must have one row of nbuckets counts per rank, nbuckets a multiple of world");
@@ -27,7 +45,7 @@ WaveLayout wave_layout(const Table& table, int world, int nbuckets, int align)
     for (int d = 0; d < world; ++d) {
         std::uint64_t at = 0, total = 0;
         for (int w = 0; w < waves; ++w) {
-            at = (at + a - 1) / a * a;
+            if (grouping == 0 || (w & (w - 1)) == 0) at = (at + a - 1) / a * a;      // doubling groups: only waves 0, 1, 2, 4, 8, ... start aligned
             out.start[d][w] = at;
             const int b = d * waves + w;
             for (int src = 0; src < world; ++src) {
@@ -251,11 +269,28 @@ int put_plan(const shardplan::ExchangePlan& p, int world, std::uint64_t* send, s
 
 extern "C" {
 
-int rsxh_plan_wave_layout(const std::uint64_t* table, int world, int nbuckets, int align, std::uint64_t* start, std::uint64_t* offset, std::uint64_t* load,
-                          std::uint64_t* extent)
+int rsxh_plan_wave_groups(int waves, int grouping, int* groups_out)
+{
+    if (waves < 1 || !groups_out || (grouping != 0 && grouping != 1)) return -1;
+    const auto groups = shardplan::wave_groups(waves, grouping);
+    for (std::size_t i = 0; i < groups.size(); ++i) {
+        groups_out[2 * i] = groups[i].first;
+        groups_out[2 * i + 1] = groups[i].second;
+    }
+    return static_cast<int>(groups.size());
+}
+
+int rsxh_plan_group_pass_units(int key_bits, int partition_bits, int group_waves)
+{
+    return shardplan::group_pass_units(key_bits, partition_bits, group_waves);
+}
+
+int rsxh_plan_wave_layout(const std::uint64_t* table, int world, int nbuckets, int align, int grouping, std::uint64_t* start, std::uint64_t* offset,
+                          std::uint64_t* load, std::uint64_t* extent)
 {
     try {
-        const shardplan::WaveLayout l = shardplan::wave_layout(to_table(table, world, nbuckets), world, nbuckets, align);
+        if (grouping != 0 && grouping != 1) return -1;
+        const shardplan::WaveLayout l = shardplan::wave_layout(to_table(table, world, nbuckets), world, nbuckets, align, grouping);
         const int waves = nbuckets / world;
         for (int d = 0; d < world; ++d) {
             for (int w = 0; w < waves; ++w) {

@@ -9,6 +9,7 @@
 
 #include <cstdint>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace shardplan {
@@ -23,15 +24,24 @@ struct ExchangePlan {
 };
 
 // Receive layout of the pipelined ("waves") paths.  nbuckets = 2^bits buckets in natural order, rank r owns buckets r*k .. r*k+k-1
-// (k = nbuckets / world), wave w holds bucket r*k + w of every rank.  At destination d the waves follow each other, each starting on a
-// multiple of `align` keys, and inside a wave the sources follow each other in rank order.
+// (k = nbuckets / world), wave w holds bucket r*k + w of every rank.  At destination d the waves follow each other and inside a wave the
+// sources follow each other in rank order.  grouping 0: every wave starts on a multiple of `align` keys (each wave is sorted by itself).
+// grouping 1 ("doubling groups"): only waves 0, 1, 2, 4, 8, ... do — the waves of a group {0} {1} {2,3} {4..7} {8..15} are contiguous
+// without gaps and are sorted TOGETHER once the group's last wave has landed: a group of 2^j aligned buckets still shares the top
+// bits - j key bits, so up to 4 buckets cost no extra pass unit at bits = 6, and the later, larger sorts run at the big-sort rate while
+// the exposed first wave stays 1/k of the exchange.
 struct WaveLayout {
     std::vector<std::vector<std::uint64_t>> start;                  // [destination][wave]  first slot of the wave
     std::vector<std::vector<std::vector<std::uint64_t>>> offset;    // [destination][wave][source]  first slot of that source's keys
     std::vector<std::uint64_t> load;                                // [destination]  keys it ends up with
     std::vector<std::uint64_t> extent;                              // [destination]  slots its receive buffer needs (alignment gaps included)
 };
-WaveLayout wave_layout(const Table& table, int world, int nbuckets, int align = 4);
+WaveLayout wave_layout(const Table& table, int world, int nbuckets, int align = 4, int grouping = 0);
+
+/// (first wave, number of waves) of every group the local sorts take together: grouping 0 -> k groups of one wave; 1 -> {0} {1} {2,3} {4..7} ...
+std::vector<std::pair<int, int>> wave_groups(int waves, int grouping);
+/// 4-bit pass units the local sort of a group of `group_waves` waves needs (its keys share the top partition_bits - log2(group_waves) bits).
+int group_pass_units(int key_bits, int partition_bits, int group_waves);
 
 // Bucket -> rank as contiguous ranges cut where the running total crosses k/world of all keys.
 std::vector<int> balanced_owner(const std::vector<std::uint64_t>& totals, int world);
@@ -70,8 +80,11 @@ std::vector<PeerAccess> peer_access_plan(const std::vector<PeerIdentity>& ranks,
 
 // ---- C entry points (ctypes; all tables row-major uint64) -------------------------------------------------------------------------
 extern "C" {
-int rsxh_plan_wave_layout(const std::uint64_t* table, int world, int nbuckets, int align, std::uint64_t* start, std::uint64_t* offset, std::uint64_t* load,
-                          std::uint64_t* extent);
+int rsxh_plan_wave_layout(const std::uint64_t* table, int world, int nbuckets, int align, int grouping, std::uint64_t* start, std::uint64_t* offset,
+                          std::uint64_t* load, std::uint64_t* extent);
+// groups_out: 2 ints per group (first wave, waves), at most `waves` groups; returns the number of groups (or -1)
+int rsxh_plan_wave_groups(int waves, int grouping, int* groups_out);
+int rsxh_plan_group_pass_units(int key_bits, int partition_bits, int group_waves);
 int rsxh_plan_balanced_owner(const std::uint64_t* totals, int nbuckets, int world, int* owner);
 int rsxh_plan_from_table(const std::uint64_t* table, int world, int nbuckets, int rank, std::uint64_t* send, std::uint64_t* recv, std::uint64_t* loads,
                          double* imbalance);

@@ -29,7 +29,9 @@ def _load() -> C.CDLL:
     lib = C.CDLL(HOST_LIB_PATH)
     U64P, I, U64 = C.POINTER(C.c_uint64), C.c_int, C.c_uint64
     sig = {
-        "rsxh_plan_wave_layout": [U64P, I, I, I, U64P, U64P, U64P, U64P],
+        "rsxh_plan_wave_layout": [U64P, I, I, I, I, U64P, U64P, U64P, U64P],
+        "rsxh_plan_wave_groups": [I, I, C.POINTER(I)],
+        "rsxh_plan_group_pass_units": [I, I, I],
         "rsxh_plan_balanced_owner": [U64P, I, I, C.POINTER(I)],
         "rsxh_plan_from_table": [U64P, I, I, I, U64P, U64P, U64P, C.POINTER(C.c_double)],
         "rsxh_plan_choose_splitters": [U64P, C.POINTER(C.c_uint32), U64P, I, I, U64P, C.POINTER(I)],
@@ -75,29 +77,47 @@ class CapacityError(RuntimeError):
     any key moves (the verdict only depends on gathered data)."""
 
 
-def wave_layout(table: list[list[int]], world_size: int, nbuckets: int = 16, align: int = 4):
+GROUP_SINGLE, GROUP_DOUBLING = 0, 1
+
+
+def wave_groups(waves: int, grouping: int = GROUP_SINGLE) -> list[tuple[int, int]]:
+    """(first wave, number of waves) of every group the local sorts take together: single -> one wave each; doubling -> {0} {1} {2,3} {4..7} ..."""
+    out = (C.c_int * (2 * max(waves, 1)))()
+    n = _load().rsxh_plan_wave_groups(waves, grouping, out)
+    if n < 0:
+        raise ValueError("wave_groups: bad arguments")
+    return [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(n)]
+
+
+def group_pass_units(key_bits: int, partition_bits: int, group_waves: int = 1) -> int:
+    """4-bit pass units the local sort of a group of `group_waves` waves needs: its keys share the top partition_bits - log2(group_waves) bits."""
+    return int(_load().rsxh_plan_group_pass_units(key_bits, partition_bits, group_waves))
+
+
+def wave_layout(table: list[list[int]], world_size: int, nbuckets: int = 16, align: int = 4, grouping: int = GROUP_SINGLE):
     """Where everything lands in the receive buffers of the pipelined paths, from the gathered [source][bucket] count table
     (natural bucket order: rank r owns buckets r*k .. r*k+k-1, k = nbuckets / world; wave w = bucket r*k+w of every rank): at
-    destination d the waves follow each other, each starting on a multiple of `align` keys (16 bytes: the local sort loads 16
-    bytes per lane), and inside a wave the sources follow each other in rank order.  Returns (start[d][w], offset[d][w][s], load[d])."""
+    destination d the waves follow each other, inside a wave the sources follow each other in rank order; a wave (grouping
+    single) or only the first wave of a doubling group starts on a multiple of `align` keys (16 bytes: the local sort loads 16
+    bytes per lane).  Returns (start[d][w], offset[d][w][s], load[d])."""
     flat, world, nb = _flat([row[:nbuckets] for row in table])
     if world != world_size or nb != nbuckets:
         raise ValueError("wave_layout: one row of nbuckets counts per rank")
     waves = nbuckets // world
     start, offset, load, extent = (C.c_uint64 * (world * waves))(), (C.c_uint64 * (world * waves * world))(), (C.c_uint64 * world)(), (C.c_uint64 * world)()
-    if _load().rsxh_plan_wave_layout(flat, world, nbuckets, align, start, offset, load, extent) != 0:
+    if _load().rsxh_plan_wave_layout(flat, world, nbuckets, align, grouping, start, offset, load, extent) != 0:
         raise ValueError("wave_layout: nbuckets must be a multiple of the world size")
     st = [[int(start[d * waves + w]) for w in range(waves)] for d in range(world)]
     of = [[[int(offset[(d * waves + w) * world + s]) for s in range(world)] for w in range(waves)] for d in range(world)]
     return st, of, [int(v) for v in load]
 
 
-def wave_extents(table: list[list[int]], world_size: int, nbuckets: int, align: int = 4) -> list[int]:
+def wave_extents(table: list[list[int]], world_size: int, nbuckets: int, align: int = 4, grouping: int = GROUP_SINGLE) -> list[int]:
     """Slots every destination's receive buffer needs for wave_layout's placement (alignment gaps included)."""
     flat, world, nb = _flat([row[:nbuckets] for row in table])
     waves = nbuckets // world
     start, offset, load, extent = (C.c_uint64 * (world * waves))(), (C.c_uint64 * (world * waves * world))(), (C.c_uint64 * world)(), (C.c_uint64 * world)()
-    if _load().rsxh_plan_wave_layout(flat, world, nbuckets, align, start, offset, load, extent) != 0:
+    if _load().rsxh_plan_wave_layout(flat, world, nbuckets, align, grouping, start, offset, load, extent) != 0:
         raise ValueError("wave_extents: nbuckets must be a multiple of the world size")
     return [int(v) for v in extent]
 

@@ -24,14 +24,30 @@ class CapacityError(RuntimeError):
     pass
 
 
-def wave_layout(table, world_size, nbuckets=16, align=4):
+def wave_groups(waves, grouping=0):
+    if grouping == 0:
+        return [(w, 1) for w in range(waves)]
+    out, w = [], 0
+    while w < waves:
+        g = 1 if w < 2 else w
+        out.append((w, min(g, waves - w)))
+        w += g
+    return out
+
+
+def group_pass_units(key_bits, partition_bits, group_waves=1):
+    return (key_bits - (partition_bits - (group_waves - 1).bit_length()) + 3) // 4
+
+
+def wave_layout(table, world_size, nbuckets=16, align=4, grouping=0):
     """table[source][bucket] in natural bucket order; rank r owns buckets r*k .. r*k+k-1, wave w = bucket r*k+w of every rank."""
     k = nbuckets // world_size
     start, offset, load, extent = [], [], [], []
     for d in range(world_size):
         at, st, of, total = 0, [], [], 0
         for w in range(k):
-            at = (at + align - 1) // align * align
+            if grouping == 0 or w & (w - 1) == 0:
+                at = (at + align - 1) // align * align
             st.append(at)
             row = []
             for src in range(world_size):

@@ -199,7 +199,7 @@ def _make_full(kind, dtype, n, orc):
     return orc.dataset(kind, dtype, n, seed=77)
 
 
-def _worker(rank, world, port, dtype, kind, with_payload, n_per_rank, q, strategy="auto", partition_bits=None):
+def _worker(rank, world, port, dtype, kind, with_payload, n_per_rank, q, strategy="auto", partition_bits=None, grouping="doubling"):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -221,7 +221,7 @@ def _worker(rank, world, port, dtype, kind, with_payload, n_per_rank, q, strateg
             spay = torch.empty_like(pay)
             rpay = torch.empty(n_per_rank * world, dtype=torch.int32)
         eng = _CpuEngineDouble(dtype)
-        sorter = d.ShardedSorter(eng, rank, world, np.dtype(dtype).itemsize * 8, dist, strategy=strategy, partition_bits=partition_bits)
+        sorter = d.ShardedSorter(eng, rank, world, np.dtype(dtype).itemsize * 8, dist, strategy=strategy, partition_bits=partition_bits, wave_grouping=grouping)
         out = opay = None
         if strategy in ("auto", "waves"):
             out = torch.empty_like(recv)
@@ -267,20 +267,22 @@ def test_sharded_sort_world4(dtype, kind, with_payload, strategy):
     _run_world(4, dtype, kind, with_payload, strategy)
 
 
-@pytest.mark.parametrize("world,dtype,with_payload,bits", [(2, "uint32", True, 1), (2, "int64", False, 6), (2, "uint64", True, 8), (4, "int32", True, 2), (4, "uint32", False, 8)])
-def test_sharded_sort_partition_bits(world, dtype, with_payload, bits):
-    """The pipeline depth is a parameter: 2^bits / world waves per rank, local sorts over the remaining bits only."""
-    _run_world(world, dtype, "SeededUniform", with_payload, "waves", partition_bits=bits)
+@pytest.mark.parametrize("world,dtype,with_payload,bits,grouping", [(2, "uint32", True, 1, "doubling"), (2, "int64", False, 6, "doubling"), (2, "uint64", True, 8, "single"),
+                                                                    (4, "int32", True, 2, "single"), (4, "uint32", False, 8, "doubling"), (2, "int32", True, 5, "single")])
+def test_sharded_sort_partition_bits(world, dtype, with_payload, bits, grouping):
+    """The pipeline depth is a parameter: 2^bits / world waves per rank, sorted one by one or in doubling groups {0} {1} {2,3} {4..7} over the
+    bits the group's keys do not share."""
+    _run_world(world, dtype, "SeededUniform", with_payload, "waves", partition_bits=bits, grouping=grouping)
 
 
-def _run_world(world, dtype, kind, with_payload, strategy, partition_bits=None):
+def _run_world(world, dtype, kind, with_payload, strategy, partition_bits=None, grouping="doubling"):
     import torch.multiprocessing as mp
     from _oracle import Oracle
     n_per_rank = 3000
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, dtype, kind, with_payload, n_per_rank, q, strategy, partition_bits)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, dtype, kind, with_payload, n_per_rank, q, strategy, partition_bits, grouping)) for r in range(world)]
     for p in procs:
         p.start()
     outs = sorted((q.get(timeout=180) for _ in range(world)), key=lambda t: t[0])
@@ -468,3 +470,5 @@ def test_sorter_constructor_validates():
         d.ShardedSorter(_CpuEngineDouble("uint32"), 0, 8, 32, dist=object(), partition_bits=2)      # 4 buckets do not feed 8 ranks
     with pytest.raises(ValueError):
         d.ShardedSorter(_CpuEngineDouble("uint32"), 0, 2, 32, dist=object(), partition_bits=9)
+    with pytest.raises(ValueError):
+        d.ShardedSorter(_CpuEngineDouble("uint32"), 0, 2, 32, dist=object(), wave_grouping="triples")

@@ -65,8 +65,9 @@ def test_count_and_wave_major_scatter(rsx, oracle, dt, bits, world, payload):
         assert np.array_equal(e.download(), np.sort(keys))
 
 
-@pytest.mark.parametrize("dt,bits,world,payload", [("uint32", 6, 8, False), ("uint32", 4, 8, True), ("int64", 8, 4, True), ("uint64", 5, 2, False), ("int32", 8, 16, False)])
-def test_device_plan_and_push_fill_every_receive_buffer(rsx, oracle, dt, bits, world, payload):
+@pytest.mark.parametrize("dt,bits,world,payload,grouping", [("uint32", 6, 8, False, 1), ("uint32", 4, 8, True, 0), ("int64", 8, 4, True, 1), ("uint64", 5, 2, False, 1), ("int32", 8, 16, False, 0),
+                                                             ("uint32", 6, 8, True, 0)])
+def test_device_plan_and_push_fill_every_receive_buffer(rsx, oracle, dt, bits, world, payload, grouping):
     """A whole world on the one GPU: every rank counts and scatters its shard, the [rank][bucket] table is assembled as the all_gather
     would, every rank plans on the device and pushes wave by wave into the receive buffers of all ranks.  Afterwards rank d's buffer holds,
     wave by wave (16-byte aligned), the keys of bucket d * k + w of rank 0, 1, ... in order — checked against numpy — and the plan the
@@ -108,13 +109,13 @@ def test_device_plan_and_push_fill_every_receive_buffer(rsx, oracle, dt, bits, w
         plans = []
         for r, e in enumerate(engines):
             side.wait_stream(torch.cuda.current_stream())
-            e.msd_plan(table.data_ptr(), stride, 256, r, side.cuda_stream if r % 2 else 0)      # odd ranks plan on a side stream
+            e.msd_plan(table.data_ptr(), stride, 256, r, side.cuda_stream if r % 2 else 0, grouping)      # odd ranks plan on a side stream
             plans.append(e.msd_plan_wait(waves, world))
             for w in range(waves):
                 e.msd_push(w, stagings[r].data_ptr(), peer_k.data_ptr(), spays[r].data_ptr() if payload else None, peer_p.data_ptr() if payload else None, parts=(r % 3) * 7)
         torch.cuda.synchronize()
         counts = [[int(v) for v in host_table[r, :1 << bits]] for r in range(world)]
-        start, offset, loads = planner.wave_layout(counts, world, 1 << bits)
+        start, offset, loads = planner.wave_layout(counts, world, 1 << bits, 4, grouping)
         top_all = (u_all >> u_all.dtype.type(kb - bits)).astype(np.int64)
         for d in range(world):
             ws, wc, ld, verdict = plans[d]

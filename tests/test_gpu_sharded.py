@@ -121,12 +121,14 @@ def _make_full(kind, dtype, n, oracle):
     ("uint64", "Skewed", False, 8, "auto"), ("int32", "Range", True, 8, "auto"), ("uint32", "Zeros", True, 8, "auto"),
     # the pipeline depth is a parameter: 2^bits / world waves per rank ("waves:bits")
     ("uint32", "SeededUniform", True, 8, "waves:3"), ("uint32", "SeededUniform", False, 8, "waves:4"), ("int64", "SeededUniform", True, 8, "waves:8"),
-    ("uint64", "SeededUniform", True, 2, "waves:1"), ("int32", "SeededUniform", False, 16, "waves:8"), ("uint32", "Random", True, 4, "waves:7")])
+    ("uint64", "SeededUniform", True, 2, "waves:1"), ("int32", "SeededUniform", False, 16, "waves:8"), ("uint32", "Random", True, 4, "waves:7"),
+    ("uint32", "SeededUniform", True, 8, "waves:6:single"), ("int64", "SeededUniform", False, 4, "waves:8:single")])
 def test_ranks_on_one_gpu(rsx, oracle, dtype, kind, with_payload, world, strategy):
     import torch
     from radix_sort_amd.distributed import ShardedSorter
-    strategy, _, bits = strategy.partition(":")
+    strategy, bits, grouping = (strategy.split(":") + ["", "doubling"])[:3] if ":" in strategy else (strategy, "", "doubling")
     bits = int(bits) if bits else None
+    grouping = grouping or "doubling"
     n = 100003
     full = _make_full(kind, dtype, n * world, oracle)
     hub = _Loopback(world)
@@ -149,7 +151,7 @@ def test_ranks_on_one_gpu(rsx, oracle, dtype, kind, with_payload, world, strateg
                 with rsx.Engine(dtype, n * world, payload=with_payload) as eng:
                     if rank % 2 == 0:
                         eng.set_stream(stream.cuda_stream)      # odd ranks leave it to the sorter, which must bind the engine to torch's current stream itself
-                    sorter = ShardedSorter(eng, rank, world, np.dtype(dtype).itemsize * 8, hub.view(rank), strategy=strategy, partition_bits=bits)
+                    sorter = ShardedSorter(eng, rank, world, np.dtype(dtype).itemsize * 8, hub.view(rank), strategy=strategy, partition_bits=bits, wave_grouping=grouping)
                     obuf = torch.empty_like(recv)
                     opay = torch.empty_like(rpay) if with_payload else None
                     n_local = sorter.sort(keys, staging, recv, pay, spay, rpay, obuf, opay)
@@ -435,16 +437,17 @@ def _shard(kind, dtype, offset, n, total):
     return out
 
 
-@pytest.mark.parametrize("strategy,partition_bits,radix_bits", [("waves", 4, 4), ("waves", 6, 4), ("waves", 6, 8), ("waves-p2p", 4, 4), ("waves-p2p", 6, 4), ("waves-p2p", 6, 8)])
-def test_config4_2pow30_uint32_over_eight_ranks_bit_exact(rsx, strategy, partition_bits, radix_bits):
+@pytest.mark.parametrize("strategy,partition_bits,radix_bits,grouping", [("waves", 4, 4, "doubling"), ("waves", 6, 4, "doubling"), ("waves", 6, 8, "single"), ("waves-p2p", 4, 4, "single"),
+                                                                          ("waves-p2p", 6, 4, "doubling"), ("waves-p2p", 6, 8, "doubling"), ("waves-p2p", 7, 4, "doubling")])
+def test_config4_2pow30_uint32_over_eight_ranks_bit_exact(rsx, strategy, partition_bits, radix_bits, grouping):
     """BASELINE config 4 at its real size and decomposition: 2^30 uint32 `Random` keys as eight contiguous shards of 2^27
     (rank r = draws r*2^27.. of the generator's stream), eight ranks with their own engine, streams and ShardedSorter — as
     eight THREADS of this one process on the box's one GPU (the pool's process guard admits at most 6 processes on a card,
     so eight rank processes cannot run here; four do: test_bench_config4_input_and_size_as_four_rank_processes), collectives
     = the loopback above with RCCL's stream semantics.  Both exchanges — all_to_all per wave, and peer stores (one push + fence per
     wave into the owners' receive buffers, the plan computed on the device) — at pipeline depths 2 (top 4 bits) and 8 (top 6 bits)
-    waves per rank, 4-bit and 8-bit local passes; the concatenation of the ranks' outputs must equal a host sort of all 2^30 keys,
-    key for key."""
+    waves per rank (and 16, top 7 bits), sorted one by one or in doubling groups {0} {1} {2,3} {4..7}, 4-bit and 8-bit local passes; the
+    concatenation of the ranks' outputs must equal a host sort of all 2^30 keys, key for key."""
     import torch
     from radix_sort_amd.distributed import ShardedSorter
     world, n = 8, 1 << 27
@@ -466,7 +469,7 @@ def test_config4_2pow30_uint32_over_eight_ranks_bit_exact(rsx, strategy, partiti
                     eng.set_stream(stream.cuda_stream)
                     if radix_bits != 4:
                         eng.set_option(rsx.OPT_RADIX_BITS, radix_bits)
-                    sorter = ShardedSorter(eng, rank, world, 32, hub.view(rank), strategy=strategy, partition_bits=partition_bits)
+                    sorter = ShardedSorter(eng, rank, world, 32, hub.view(rank), strategy=strategy, partition_bits=partition_bits, wave_grouping=grouping)
                     if p2p:
                         sorter.setup_peer_exchange(2 * n, keys.device)
                     try:
@@ -551,7 +554,7 @@ def test_peer_store_exchange_thread_ranks(rsx, oracle, dtype, with_payload, worl
                     if radix_bits != 4:
                         eng.set_option(rsx.OPT_RADIX_BITS, radix_bits)
                     sorter = ShardedSorter(eng, rank, world, np.dtype(dtype).itemsize * 8, hub.view(rank), strategy="waves-p2p",
-                                           partition_bits=bits, force_exchange=True)
+                                           partition_bits=bits, force_exchange=True, wave_grouping="single" if world == 4 else "doubling")
                     sorter.setup_peer_exchange(2 * n, keys.device, with_payload)
                     try:
                         assert sorter._peer["access"] == [planner.PEER_SELF if r == rank else planner.PEER_SAME_POINTER for r in range(world)]

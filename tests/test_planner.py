@@ -64,15 +64,40 @@ def test_wave_layout_matches_the_reference_statement():
     cases = [(w, nb, _random_table(rnd, w, nb)) for _ in range(60) for w in (1, 2, 4, 8, 16) for nb in (16, 64, 256) if nb >= w]
     cases += _dataset_tables()
     for world, nb, table in cases:
-        for align in (1, 4):
-            start, offset, load = pl.wave_layout(table, world, nb, align)
-            extent = pl.wave_extents(table, world, nb, align)
-            want = ref.wave_layout(table, world, nb, align)
+        for align, grouping in ((1, 0), (4, 0), (4, 1)):
+            start, offset, load = pl.wave_layout(table, world, nb, align, grouping)
+            extent = pl.wave_extents(table, world, nb, align, grouping)
+            want = ref.wave_layout(table, world, nb, align, grouping)
             assert (start, offset, load, extent) == want
+            if grouping:            # inside a group the waves lie gap-free; a group starts on a multiple of `align`
+                for first, count in pl.wave_groups(nb // world, grouping):
+                    for d in range(world):
+                        assert start[d][first] % align == 0
+                        for w in range(first, first + count - 1):
+                            assert start[d][w + 1] == start[d][w] + sum(table[s][d * (nb // world) + w] for s in range(world))
     with pytest.raises(ValueError):
         pl.wave_layout([[1] * 16] * 3, 3, 16)          # 16 buckets do not divide over 3 ranks
     with pytest.raises(ValueError):
         pl.wave_layout([[1] * 16, [1] * 15], 2, 16)    # ragged
+
+
+def test_wave_groups_and_pass_units():
+    pl = _planner()
+    assert pl.wave_groups(8, pl.GROUP_DOUBLING) == [(0, 1), (1, 1), (2, 2), (4, 4)] and pl.wave_groups(1, 1) == [(0, 1)] and pl.wave_groups(2, 1) == [(0, 1), (1, 1)]
+    assert pl.wave_groups(16, 1)[-1] == (8, 8) and pl.wave_groups(4, pl.GROUP_SINGLE) == [(0, 1), (1, 1), (2, 1), (3, 1)]
+    for waves in (1, 2, 4, 8, 16, 32, 64, 128, 256):
+        for grouping in (0, 1):
+            groups = pl.wave_groups(waves, grouping)
+            assert groups == ref.wave_groups(waves, grouping)
+            assert [f for f, _ in groups] == [sum(c for _, c in groups[:i]) for i in range(len(groups))] and sum(c for _, c in groups) == waves
+            for first, count in groups:
+                assert first % count == 0                    # an aligned block of buckets: its keys share the top bits - log2(count) bits
+    # 8 ranks on the top 6 bits: groups of up to 4 buckets still need 7 pass units of a 32-bit key, like a single bucket
+    assert [pl.group_pass_units(32, 6, g) for g in (1, 2, 4)] == [7, 7, 7] and pl.group_pass_units(32, 6, 8) == 8
+    for kb in (32, 64):
+        for bits in range(1, 9):
+            for g in (1, 2, 4, 8, 16):
+                assert pl.group_pass_units(kb, bits, g) == ref.group_pass_units(kb, bits, g) == -(-(kb - bits + (g - 1).bit_length()) // 4)
 
 
 def test_exchange_plans_match_the_reference_statement():
