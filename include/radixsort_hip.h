@@ -307,8 +307,8 @@ int rsx_peer_enable(rsx_engine* e, int peer_device);
  *                    travel while wave w is sorted on the engine's; the call makes it wait for the plan and for rsx_msd_scatter itself.
  *                    The caller fences the wave across ranks (one tiny all_reduce, or its own flags) before sorting it.
  * Plumbing for hosts that do not link HIP themselves: rsx_copy_to_device / _from_device / _on_device (asynchronous on the engine's
- * stream; pageable host memory serialises, pin it with rsx_pin_host) and rsx_wait_for (e's stream waits for everything enqueued on
- * other's stream so far — engines of one process, any devices). */
+ * stream; pageable host memory serialises, pin it with rsx_pin_host), rsx_wait_for (e's stream waits for everything enqueued on
+ * other's stream so far — engines of one process, any devices) and rsx_record_mark / rsx_wait_mark (below). */
 int rsx_msd_count(rsx_engine* e, const void* d_keys, uint64_t n, int bits, int world, uint64_t* d_counts);
 int rsx_msd_scatter(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n, void* d_staging, uint32_t* d_staging_payload);
 int rsx_msd_plan(rsx_engine* e, const uint64_t* d_table, uint32_t stride, uint32_t cap_at, int rank, int grouping, void* hip_stream);
@@ -319,6 +319,12 @@ int rsx_copy_to_device(rsx_engine* e, void* d_dst, const void* host_src, uint64_
 int rsx_copy_from_device(rsx_engine* e, void* host_dst, const void* d_src, uint64_t bytes);
 int rsx_copy_on_device(rsx_engine* e, void* d_dst, const void* d_src, uint64_t bytes);
 int rsx_wait_for(rsx_engine* e, rsx_engine* other);
+/* Named points of an engine's stream: rsx_record_mark(e, slot) marks "everything enqueued on e's stream so far" (slot 0..RSX_MAX_MARKS-1, re-recordable);
+ * rsx_wait_mark(e, other, slot) makes e's stream wait for other's mark — at any later time, whatever has been enqueued on other's stream since
+ * (rsx_wait_for = record + wait in one call).  Used by the C++ sharded driver: one mark per wave on the communication stream. */
+#define RSX_MAX_MARKS 256
+int rsx_record_mark(rsx_engine* e, int slot);
+int rsx_wait_mark(rsx_engine* e, rsx_engine* other, int slot);
 int rsx_key_range(rsx_engine* e, const void* d_keys, uint64_t n, uint64_t* lo, uint64_t* hi);
 int rsx_partition_range(rsx_engine* e, const void* d_keys, const uint32_t* d_payload, uint64_t n, uint64_t lo, int shift, uint64_t mul,
                         void* d_keys_out, uint32_t* d_payload_out, uint64_t* bucket_offsets);

@@ -43,7 +43,7 @@ SYMBOLS = [
     "rsx_create", "rsx_destroy", "rsx_set_stream", "rsx_get_stream", "rsx_set_option", "rsx_get_geometry", "rsx_resize",
     "rsx_upload", "rsx_fill_pad", "rsx_download", "rsx_pin_host", "rsx_unpin_host", "rsx_pipeline_submit", "rsx_pipeline_wait", "rsx_host_device_pointer",
     "rsx_histogram", "rsx_scan", "rsx_paste", "rsx_reorder", "rsx_sort", "rsx_sync", "rsx_check_status",
-    "rsx_sort_from", "rsx_partition", "rsx_partition_count", "rsx_partition_scatter", "rsx_sample_keys", "rsx_partition_count_split", "rsx_partition_scatter_split", "rsx_peer_alloc", "rsx_peer_free", "rsx_peer_open", "rsx_peer_close", "rsx_peer_enable", "rsx_sort_from_to", "rsx_msd_count", "rsx_msd_scatter", "rsx_msd_plan", "rsx_msd_plan_wait", "rsx_msd_push", "rsx_copy_to_device", "rsx_copy_from_device", "rsx_copy_on_device", "rsx_wait_for", "rsx_key_range", "rsx_partition_range", "rsx_result_device", "rsx_copy_result", "rsx_tile_map", "rsx_timings",
+    "rsx_sort_from", "rsx_partition", "rsx_partition_count", "rsx_partition_scatter", "rsx_sample_keys", "rsx_partition_count_split", "rsx_partition_scatter_split", "rsx_peer_alloc", "rsx_peer_free", "rsx_peer_open", "rsx_peer_close", "rsx_peer_enable", "rsx_sort_from_to", "rsx_msd_count", "rsx_msd_scatter", "rsx_msd_plan", "rsx_msd_plan_wait", "rsx_msd_push", "rsx_copy_to_device", "rsx_copy_from_device", "rsx_copy_on_device", "rsx_wait_for", "rsx_record_mark", "rsx_wait_mark", "rsx_key_range", "rsx_partition_range", "rsx_result_device", "rsx_copy_result", "rsx_tile_map", "rsx_timings",
 ]
 
 
@@ -157,6 +157,8 @@ def load_library() -> C.CDLL:
         "rsx_copy_from_device": ([P, P, P, U64], I),
         "rsx_copy_on_device": ([P, P, P, U64], I),
         "rsx_wait_for": ([P, P], I),
+        "rsx_record_mark": ([P, I], I),
+        "rsx_wait_mark": ([P, P, I], I),
         "rsx_key_range": ([P, P, U64, C.POINTER(U64), C.POINTER(U64)], I),
         "rsx_partition_range": ([P, P, P, U64, U64, I, U64, P, P, C.POINTER(U64)], I),
         "rsx_result_device": ([P, C.POINTER(P), C.POINTER(P)], I),
@@ -437,6 +439,14 @@ class Engine:
     def wait_for(self, other: "Engine") -> None:
         """This engine's stream waits for everything enqueued on `other`'s stream so far."""
         self._check(self.lib.rsx_wait_for(self._h, other._h), "rsx_wait_for")
+
+    def record_mark(self, slot: int) -> None:
+        """Marks "everything enqueued on this engine's stream so far" under `slot` (0..255)."""
+        self._check(self.lib.rsx_record_mark(self._h, slot), "rsx_record_mark")
+
+    def wait_mark(self, other: "Engine", slot: int) -> None:
+        """This engine's stream waits for `other`'s mark `slot`."""
+        self._check(self.lib.rsx_wait_mark(self._h, other._h, slot), "rsx_wait_mark")
 
     def key_range(self, d_keys: int, n: int) -> tuple[int, int]:
         lo, hi = C.c_uint64(), C.c_uint64()

@@ -185,6 +185,7 @@ struct rsx_engine {
     hipEvent_t msd_event = nullptr;             // the plan (and its copy to the host) is complete
     hipEvent_t msd_scatter_event = nullptr;     // rsx_msd_scatter has filled the staging buffer (pushes on another stream wait for it)
     bool msd_scattered = false;
+    hipEvent_t marks[RSX_MAX_MARKS] = {};        // rsx_record_mark / rsx_wait_mark
     std::map<int, hipEvent_t> order_events;     // rsx_wait_for: this engine's events, one per device of the engines it has waited for
     const void* msd_keys = nullptr;             // rsx_msd_count left table8 / cbase8 for exactly this input ...
     uint64_t msd_n = 0;
@@ -1451,6 +1452,7 @@ int rsx_destroy(rsx_engine* e)
     if (e->msd_event) (void)hipEventDestroy(e->msd_event);
     if (e->msd_scatter_event) (void)hipEventDestroy(e->msd_scatter_event);
     for (auto& kv : e->order_events) if (kv.second) (void)hipEventDestroy(kv.second);
+    for (hipEvent_t ev : e->marks) if (ev) (void)hipEventDestroy(ev);
     if (e->range_dev && hipFree(e->range_dev) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->ref_table && hipFree(e->ref_table) != hipSuccess) status = RSX_CLEANUP_FAILED;
     if (e->ref_globsum && hipFree(e->ref_globsum) != hipSuccess) status = RSX_CLEANUP_FAILED;

@@ -533,14 +533,15 @@ class ShardedSorter:
                 works = call()
             pending.append((works, at, n_recv))
 
-        # the next group's waves are issued before this group's sort is enqueued
+        # issue order: the first group's waves, (below) the first group's sort, then EVERY remaining wave — the exchange runs back to back, as
+        # early as the links allow — then the remaining sorts
         while state["next"] < groups[0][0] + groups[0][1]:
             issue()
         self._mark("plan")
         done = 0
         for g, (first, nwaves) in enumerate(groups):
-            if g + 1 < len(groups):
-                while state["next"] < groups[g + 1][0] + groups[g + 1][1]:
+            if g == 1:
+                while state["next"] < k:
                     issue()
             n_group = 0
             for w in range(first, first + nwaves):
@@ -582,7 +583,7 @@ class ShardedSorter:
         with torch.cuda.stream(self._push):
             work.wait()
             self.engine.msd_plan(table.data_ptr(), ROW_LEN, ROW_CAPS, self.rank, self._push.cuda_stream, self.grouping)
-        for w in range(groups[0][0] + groups[0][1]):      # the first group now; every later group before the sort of the one in front of it
+        for w in range(groups[0][0] + groups[0][1]):      # the first group now; the rest right after the first group's sort has been enqueued
             push(w)
         wave_start, wave_count, loads, verdict = self.engine.msd_plan_wait(k, world)
         self.last_imbalance = max(loads) / max(1.0, sum(loads) / world)
@@ -596,8 +597,8 @@ class ShardedSorter:
         done = 0
         bits = self.partition_bits
         for g, (first, nwaves) in enumerate(groups):
-            if g + 1 < len(groups):
-                for w in range(len(fences), groups[g + 1][0] + groups[g + 1][1]):
+            if g == 1:
+                for w in range(len(fences), k):          # every remaining wave now: the pushes run back to back beside the sorts
                     push(w)
             for w in range(first, first + nwaves):
                 if fences[w] is not None:

@@ -503,24 +503,31 @@ int RadixSortMultiGPU<T>::pipelinedAllToAll(Rank& r, std::uint64_t)
     const double imbalance = static_cast<double>(*std::max_element(layout.load.begin(), layout.load.end())) / std::max(1.0, static_cast<double>(total) / mWorld);
     const bool fits = shardplan::check_capacity_extent(layout.extent, layout.load, recvCaps, outCaps) < 0;
     if (!fits || imbalance > mOpt.maxImbalance) return -1;      // same verdict on every rank: it only depends on the gathered table
-    // the next group's waves are handed to the communicator before this group's sort is enqueued: the links and the CUs work side by side
+    // Issue order: the first group's waves, the first group's sort, then EVERY remaining wave (the exchange runs back to back, as early as the links
+    // allow, each wave closed by a mark on the communication stream), then the remaining sorts, each behind the mark of its group's last wave.
     const auto groups = shardplan::wave_groups(k, mGrouping);
     std::uint64_t sendAt = 0, done = 0;
     int issued = 0;
+    auto issueUpTo = [&](int end) {
+        for (; issued < end; ++issued) {
+            int rc = exchangeWave(r, issued, counts, layout, sendAt);
+            if (rc == RSX_OK) rc = rsx_record_mark(r.C, issued);
+            if (rc != RSX_OK) return rc;
+        }
+        return static_cast<int>(RSX_OK);
+    };
     RSX_STEP(rsx_wait_for(r.C, r.E), "rsx_wait_for");                                   // the staging buffer is complete
-    for (; issued < groups[0].first + groups[0].second; ++issued) RSX_STEP(exchangeWave(r, issued, counts, layout, sendAt), "exchange of a wave");
+    RSX_STEP(issueUpTo(groups[0].first + groups[0].second), "exchange of a wave");
     for (std::size_t g = 0; g < groups.size(); ++g) {
         const int first = groups[g].first, waves = groups[g].second;
-        RSX_STEP(rsx_wait_for(r.E, r.C), "rsx_wait_for");                               // every wave of this group has landed
-        if (g + 1 < groups.size()) {
-            for (; issued < groups[g + 1].first + groups[g + 1].second; ++issued) RSX_STEP(exchangeWave(r, issued, counts, layout, sendAt), "exchange of a wave");
-        }
+        RSX_STEP(rsx_wait_mark(r.E, r.C, first + waves - 1), "rsx_wait_mark");          // every wave of this group has landed
         std::uint64_t cnt = 0;
         for (int w = first; w < first + waves; ++w) {
             for (const auto& row : counts) cnt += row[static_cast<std::size_t>(r.rank * k + w)];
         }
         RSX_STEP(sortWaves(r, layout.start[static_cast<std::size_t>(r.rank)][static_cast<std::size_t>(first)], cnt, done, waves), "local sort of a group of waves");
         done += cnt;
+        if (g == 0) RSX_STEP(issueUpTo(k), "exchange of a wave");
     }
     r.nOut = done;
     r.path = "waves";
@@ -543,7 +550,15 @@ int RadixSortMultiGPU<T>::pipelinedPeerStores(Rank& r)
     };
     const auto groups = shardplan::wave_groups(k, mGrouping);
     int issued = 0;
-    for (; issued < groups[0].first + groups[0].second; ++issued) RSX_STEP(push(issued), "push of a wave");
+    auto issueUpTo = [&](int end) {
+        for (; issued < end; ++issued) {
+            int rc = push(issued);
+            if (rc == RSX_OK) rc = rsx_record_mark(r.C, issued);
+            if (rc != RSX_OK) return rc;
+        }
+        return static_cast<int>(RSX_OK);
+    };
+    RSX_STEP(issueUpTo(groups[0].first + groups[0].second), "push of a wave");
     std::vector<std::uint64_t> start(static_cast<std::size_t>(k)), count(start.size()), loads(static_cast<std::size_t>(mWorld));
     std::uint64_t verdict = 0;
     RSX_STEP(rsx_msd_plan_wait(r.E, start.data(), count.data(), loads.data(), &verdict), "rsx_msd_plan_wait");      // the host's one wait: its own wave sizes
@@ -557,14 +572,12 @@ int RadixSortMultiGPU<T>::pipelinedPeerStores(Rank& r)
     std::uint64_t done = 0;
     for (std::size_t g = 0; g < groups.size(); ++g) {
         const int first = groups[g].first, waves = groups[g].second;
-        RSX_STEP(rsx_wait_for(r.E, r.C), "rsx_wait_for");            // every wave of this group has landed here
-        if (g + 1 < groups.size()) {
-            for (; issued < groups[g + 1].first + groups[g + 1].second; ++issued) RSX_STEP(push(issued), "push of a wave");
-        }
+        RSX_STEP(rsx_wait_mark(r.E, r.C, first + waves - 1), "rsx_wait_mark");          // every wave of this group has landed here
         std::uint64_t cnt = 0;
         for (int w = first; w < first + waves; ++w) cnt += count[static_cast<std::size_t>(w)];
         RSX_STEP(sortWaves(r, start[static_cast<std::size_t>(first)], cnt, done, waves), "local sort of a group of waves");
         done += cnt;
+        if (g == 0) RSX_STEP(issueUpTo(k), "push of a wave");          // every remaining wave now: the pushes run back to back beside the sorts
     }
     r.nOut = done;
     r.path = "waves-p2p";
