@@ -784,6 +784,7 @@ template <typename Key>
 int launch_reorder8(rsx_engine* e, const void* in, void* out, const uint32_t* pin, uint32_t* pout, uint64_t count, const Grid& g, uint32_t chunk_groups, int shift)
 {
     const Key flip = flip_mask<Key>(e);
+    e->last_in = nullptr;            // an 8-bit pass has no counterpart in the reference's geometry: RSX_OPT_REF_DIAGNOSTICS refuses after it (a later 4-bit pass sets it again)
     const bool packed = sizeof(Key) == 4 && e->has_payload && e->r8_packed;
     const bool wide = r8_wide_for(e, sizeof(Key) == 8, e->has_payload);
     const size_t wide_extra = e->r8_extra_lds >= 0 ? static_cast<size_t>(e->r8_extra_lds) : 0;      // (57-62 KiB per workgroup: two per CU as they stand)
@@ -900,9 +901,7 @@ int sort8_chain_enqueue(rsx_engine* e, const void* ext_keys, const uint32_t* ext
                 rc = launch_reorder8<Key>(e, in, out, pin, pout, count, g, s.chunk_groups, shift);
         }
         if (rc != RSX_OK) return rc;
-        e->last_in = in;
-        e->last_shift = shift + RSX_RADIX_BITS;       // (the reference-geometry diagnostics are those of 4-bit passes; not meaningful here)
-        in = out;
+        in = out;                                     // (launch_reorder8 cleared last_in: the reference-geometry diagnostics describe 4-bit passes, rsx_download refuses them after this chain)
         pin = pout;
         dst ^= 1;
     }
@@ -1673,7 +1672,7 @@ int rsx_download(rsx_engine* e, void* host_keys_out, uint32_t* host_perm_out, ui
     if (e->ref_diag && ((hist_out && hist_cap) || (globsum_out && globsum_cap))) {
         // the reference's m_hHistograms / m_hGlobsum: recomputed in its own geometry from the last pass's input
         if (e->n == 0 || e->n % rsx::kRefVps != 0 || !e->last_in)
-            return fail(RSX_DATA_DOWNLOAD_FAILED, "rsx_download: reference-geometry diagnostics need a finished pass over a multiple of 1024 keys");
+            return fail(RSX_DATA_DOWNLOAD_FAILED, "rsx_download: reference-geometry diagnostics (RSX_OPT_REF_DIAGNOSTICS) need a finished 4-BIT pass over a multiple of 1024 keys as the last pass of the sort");
         if (e->key_bytes == 4) {
             hipLaunchKernelGGL(rsx::ref_histogram_kernel<uint32_t>, dim3(rsx::kRefVps), dim3(256), 0, e->stream,
                                static_cast<const uint32_t*>(e->last_in), e->ref_table, e->n, e->last_shift, flip_mask<uint32_t>(e));
@@ -1698,9 +1697,9 @@ int rsx_download(rsx_engine* e, void* host_keys_out, uint32_t* host_perm_out, ui
     // launches, the 4096-key self-scan chain, the one-workgroup sort); sorts on 1024-key tiles and 8-bit passes leave none, and
     // handing out what an earlier sort left would be silently wrong.  RSX_OPT_REF_DIAGNOSTICS rebuilds its tables for any path.
     if (hist_out && hist_cap && e->n > 0 && !e->table_valid)
-        return fail(RSX_DATA_DOWNLOAD_FAILED, "rsx_download: the last sort left no table in the engine's [digit][tile] geometry (tiles of 1024 keys or 8-bit digits); use RSX_OPT_REF_DIAGNOSTICS, or RSX_OPT_SMALL_TILE_MAX_KEYS = 0 / 4-bit digits");
+        return fail(RSX_DATA_DOWNLOAD_FAILED, "rsx_download: the last sort left no table in the engine's [digit][tile] geometry (tiles of 1024 keys, or 8-bit digits); with 4-bit digits use RSX_OPT_REF_DIAGNOSTICS (the reference-geometry tables, 4-bit passes only) or RSX_OPT_SMALL_TILE_MAX_KEYS = 0; 8-bit passes have no such table");
     if (globsum_out && globsum_cap && e->n > 0 && !e->globsum_valid)
-        return fail(RSX_DATA_DOWNLOAD_FAILED, "rsx_download: the last sort's table scan produced no group sums (self-scan, one-workgroup scan or 8-bit digits); use RSX_OPT_REF_DIAGNOSTICS, or the chain with scan launches");
+        return fail(RSX_DATA_DOWNLOAD_FAILED, "rsx_download: the last sort's table scan produced no group sums (self-scan, one-workgroup scan, or 8-bit digits); with 4-bit digits use RSX_OPT_REF_DIAGNOSTICS (4-bit passes only) or the chain with scan launches; 8-bit passes have no group sums in this geometry");
     if (hist_out && hist_cap) {
         const uint64_t live = static_cast<uint64_t>(RSX_RADIX) * e->ntiles(e->n);
         const uint64_t take = std::min(hist_cap, live);

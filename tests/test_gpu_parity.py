@@ -1053,6 +1053,23 @@ def test_download_refuses_tables_the_last_sort_did_not_produce(mod, oracle):
         e.sort()
         got, table, gs = e.download(hist_cap=16384, globsum_cap=512)
         assert np.array_equal(got, want_sorted) and np.array_equal(table, want_table) and np.array_equal(gs, want_gs)
+        # the reference-geometry diagnostics describe a 4-BIT last pass: after an 8-bit sort they are refused, not recomputed from stale state
+    with mod.Engine("uint32", 1 << 20) as e:                              # (8-bit passes run from 2^19 keys; below, the 4-bit self-scan chain serves either setting)
+        wide = oracle.dataset("SeededUniform", "uint32", 1 << 20, seed=12)
+        e.set_option(mod.OPT_REF_DIAGNOSTICS, 1)
+        e.set_option(mod.OPT_RADIX_BITS, 8)
+        e.upload(wide)
+        e.sort()
+        with pytest.raises(mod.RadixSortError) as err:
+            e.download(hist_cap=16384, globsum_cap=512)
+        assert "4-BIT pass" in str(err.value)
+        assert np.array_equal(e.download(), np.sort(wide))                 # the keys themselves are fine
+        e.set_option(mod.OPT_RADIX_BITS, 4)
+        e.upload(wide)
+        e.sort()
+        _, table, gs = e.download(hist_cap=16384, globsum_cap=512)
+        _, want_table2, want_gs2 = oracle.emulate_reference_gpu(wide)
+        assert np.array_equal(table, want_table2) and np.array_equal(gs, want_gs2)
 
 
 def test_graph_capture_with_8bit_digits_allocates_outside_the_capture(mod, oracle):
