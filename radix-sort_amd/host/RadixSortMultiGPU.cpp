@@ -213,7 +213,8 @@ void RadixSortMultiGPU<T>::stopWorkers()
 template <typename T>
 int RadixSortMultiGPU<T>::fail(Rank& r, int rc, const std::string& what)
 {
-    r.error = what + " (" + rsx_last_error() + ")";
+    // rc == RSX_OK: a verdict of this driver (another rank failed, buffers too small, ...), no C-ABI call behind it whose text would explain anything
+    r.error = rc == RSX_OK ? what : what + " (" + rsx_last_error() + ")";
     r.rc = rc == RSX_OK ? static_cast<int>(RSX_CALCULATION_FAILED) : rc;
     if (mHub) mHub->abort("rank " + std::to_string(r.rank) + ": " + r.error);      // the other ranks find out at their next rendezvous: nobody hangs
     return r.rc;
@@ -384,7 +385,7 @@ OperationStatus RadixSortMultiGPU<T>::downloadData()
 {
     const std::function<int(Rank&)> job = [this](Rank& r) -> int {
         const std::vector<std::uint64_t> loads = mHub->allGather(r.rank, r.nOut);
-        if (mHub->failed()) return fail(r, RSX_DATA_DOWNLOAD_FAILED, "another rank failed");
+        if (mHub->failed()) return fail(r, RSX_OK, "another rank failed");
         const std::uint64_t at = std::accumulate(loads.begin(), loads.begin() + r.rank, std::uint64_t{0});
         if (std::accumulate(loads.begin(), loads.end(), std::uint64_t{0}) != mTotal) return fail(r, RSX_DATA_DOWNLOAD_FAILED, "the ranks' outputs do not add up to the input");
         RSX_STEP(rsx_copy_from_device(r.E, mHostSpans.m_hResultFromGPU.data() + at, r.out, r.nOut * sizeof(T)), "download of the rank's output");
@@ -442,7 +443,7 @@ int RadixSortMultiGPU<T>::stepRank(Rank& r)
         }
         RSX_STEP(rsx_msd_count(r.E, r.keys, r.n, mBits, mWorld, r.d_row), "rsx_msd_count");
         RSX_STEP(rsx_wait_for(r.C, r.E), "rsx_wait_for");
-        const int rc = mOpt.exchange == ShardedSortOptions::Exchange::PeerStores ? pipelinedPeerStores(r) : pipelinedAllToAll(r, status);
+        const int rc = mOpt.exchange == ShardedSortOptions::Exchange::PeerStores ? pipelinedPeerStores(r) : pipelinedAllToAll(r);
         if (rc != -1) return rc;             // -1: the top bits do not balance (every rank found the same): the general path takes over
         return splitterPath(r, 0);           // (the status word has been seen by everybody in the row exchange)
     }
@@ -478,7 +479,7 @@ int RadixSortMultiGPU<T>::exchangeWave(Rank& r, int wave, const shardplan::Table
 }
 
 template <typename T>
-int RadixSortMultiGPU<T>::pipelinedAllToAll(Rank& r, std::uint64_t)
+int RadixSortMultiGPU<T>::pipelinedAllToAll(Rank& r)
 {
     const int nb = 1 << mBits, k = nb / mWorld;
     // the row to the host on the communication stream: behind the count only, the scatter runs beside it
@@ -486,7 +487,7 @@ int RadixSortMultiGPU<T>::pipelinedAllToAll(Rank& r, std::uint64_t)
     RSX_STEP(rsx_msd_scatter(r.E, r.keys, r.pay, r.n, r.staging, r.spay), "rsx_msd_scatter");
     RSX_STEP(rsx_sync(r.C), "count row to the host");
     const std::vector<Row> rows = mHub->allGather(r.rank, r.hostRow);
-    if (mHub->failed()) return fail(r, RSX_CALCULATION_FAILED, "another rank failed");
+    if (mHub->failed()) return fail(r, RSX_OK, "another rank failed");
     shardplan::Table counts(static_cast<std::size_t>(mWorld));
     std::vector<std::uint64_t> recvCaps, outCaps;
     bool anyStatus = false;
@@ -603,7 +604,7 @@ int RadixSortMultiGPU<T>::splitterPath(Rank& r, std::uint64_t status)
         RSX_STEP(rsx_sample_keys(r.E, r.keys, r.n, static_cast<std::uint32_t>(want), mine.values.data()), "rsx_sample_keys");
     }
     const std::vector<SampleSet> all = mHub->allGather(r.rank, mine);
-    if (mHub->failed()) return fail(r, RSX_CALCULATION_FAILED, "another rank failed");
+    if (mHub->failed()) return fail(r, RSX_OK, "another rank failed");
     std::vector<std::vector<std::uint64_t>> samples;
     std::vector<std::uint64_t> sizes;
     for (const SampleSet& s : all) {
@@ -622,7 +623,7 @@ int RadixSortMultiGPU<T>::splitterPath(Rank& r, std::uint64_t status)
     std::vector<std::uint64_t> counts(2 * splitters.size() + 1);
     RSX_STEP(rsx_partition_count_split(r.E, r.keys, r.n, splitters.data(), static_cast<int>(splitters.size()), counts.data()), "rsx_partition_count_split");
     const shardplan::Table table = mHub->allGather(r.rank, counts);
-    if (mHub->failed()) return fail(r, RSX_CALCULATION_FAILED, "another rank failed");
+    if (mHub->failed()) return fail(r, RSX_OK, "another rank failed");
     const shardplan::ExchangePlan plan = shardplan::split_plan(table, r.rank, mWorld);
     std::vector<std::uint64_t> caps;
     for (const Rank& o : mRanks) caps.push_back(o.cap);

@@ -102,7 +102,7 @@ private:
 
     int allocateRank(Rank& r);
     int stepRank(Rank& r);
-    int pipelinedAllToAll(Rank& r, std::uint64_t status);
+    int pipelinedAllToAll(Rank& r);
     int pipelinedPeerStores(Rank& r);
     int splitterPath(Rank& r, std::uint64_t status);
     int exchangeWave(Rank& r, int wave, const shardplan::Table& counts, const shardplan::WaveLayout& layout, std::uint64_t& sendAt);

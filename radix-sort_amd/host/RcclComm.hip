@@ -98,11 +98,14 @@ int rsxc_rccl_all_to_all_v(void* comm, int world, const void* d_send, const std:
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     NCCL_TRY(ncclGroupStart());
-    for (int p = 0; p < world; ++p) {
-        if (sendCnt[p]) NCCL_TRY(ncclSend(static_cast<const char*>(d_send) + sendOff[p] * elemBytes, sendCnt[p] * elemBytes, ncclInt8, p, c->comm, s));
-        if (recvCnt[p]) NCCL_TRY(ncclRecv(static_cast<char*>(d_recv) + recvOff[p] * elemBytes, recvCnt[p] * elemBytes, ncclInt8, p, c->comm, s));
+    ncclResult_t first = ncclSuccess;            // the group is closed whatever happens inside it
+    for (int p = 0; p < world && first == ncclSuccess; ++p) {
+        if (sendCnt[p]) first = ncclSend(static_cast<const char*>(d_send) + sendOff[p] * elemBytes, sendCnt[p] * elemBytes, ncclInt8, p, c->comm, s);
+        if (first == ncclSuccess && recvCnt[p]) first = ncclRecv(static_cast<char*>(d_recv) + recvOff[p] * elemBytes, recvCnt[p] * elemBytes, ncclInt8, p, c->comm, s);
     }
-    NCCL_TRY(ncclGroupEnd());
+    const ncclResult_t closed = ncclGroupEnd();
+    if (first != ncclSuccess) return fail("ncclSend / ncclRecv", ncclGetErrorString(first));
+    if (closed != ncclSuccess) return fail("ncclGroupEnd", ncclGetErrorString(closed));
     return 0;
 }
 
