@@ -9,9 +9,10 @@ histogram -> scan -> paste -> reorder).  At N=1 the workload is BASELINE.json co
 digits.  Inputs are resident in HBM before the timed region; nothing crosses PCIe inside
 it.  For N>1 the default workload is BASELINE.json configs[3]: 2^30 uint32 keys in total,
 2^30/N per GPU (`--log2-keys K` instead fixes 2^K keys PER GPU: weak scaling), and a step
-is: partition by top bits -> bucket-count all_gather ("histogram all-to-all") ->
-all_to_all of keys over xGMI -> local sort (radix-sort_amd/distributed.py), one rank per
-GPU over RCCL.
+is: count by the top `--partition-bits` bits -> bucket-count all_gather ("histogram
+all-to-all") beside the scatter into wave-major staging -> the keys over xGMI wave by wave
+(RCCL all_to_all, or RSX_STRATEGY=waves-p2p: peer stores) -> local sorts of the waves in
+doubling groups (radix-sort_amd/distributed.py), one rank per GPU over RCCL.
 
 `python bench.py --gpus N` from a plain shell starts the N ranks itself: the parent makes
 no GPU call, launches `python -m torch.distributed.run --nproc-per-node N bench.py ...` as
