@@ -120,8 +120,8 @@ def test_harness_with_8bit_digits():
     ["--ranks", "4", "--num-elements", "200000", "--partition-bits", "8", "--radix-bits", "8", "--with-permutation"],
     ["--ranks", "2", "--num-elements", "5000", "--partition-bits", "1", "--exchange", "peer-stores"],
     ["--ranks", "3", "--num-elements", "100000", "--with-permutation"],                                  # not a power of two: splitter path for every dataset
-    ["--sharded", "--comm", "rccl", "--num-elements", "400000", "--with-permutation"],                   # ONE rank through real RCCL (ncclCommInitAll, grouped send/recv to self)
-    ["--sharded", "--comm", "rccl", "--num-elements", "400000", "--exchange", "peer-stores"],            # ... and the ncclAllGather + ncclAllReduce fence of the peer-store path
+    ["--sharded", "--comm", "rccl", "--num-elements", "100000", "--with-permutation"],                   # ONE rank through real RCCL (ncclCommInitAll, grouped send/recv to self)
+    ["--sharded", "--comm", "rccl", "--num-elements", "100000", "--exchange", "peer-stores"],            # ... and the ncclAllGather + ncclAllReduce fence of the peer-store path
 ])
 def test_sharded_harness_matrix(extra):
     """`rsx_tests --gpus N` (here: rank THREADS on the box's one GPU, `--ranks R`): RadixSortMultiGPU<T> behind CRadixSortTask's five
