@@ -501,8 +501,8 @@ class ShardedSorter:
             self._mark("plan")
             return None
         # The waves are handed to the collective stream from a SIDE stream that waits for the scatter only (a collective orders itself behind
-        # torch's current stream: issued from the engine's stream, wave w + 1 would wait for the local sort of wave w - 1), two waves ahead of
-        # the sorts: the host never stands between the device and its next kernel, the links and the CUs work side by side.
+        # torch's current stream: issued from the engine's stream, wave w + 1 would wait for the local sort of wave w - 1): the host never stands
+        # between the device and its next kernel, the links and the CUs work side by side.
         mine = counts[self.rank]
         on_device = getattr(keys, "is_cuda", False)
         if on_device:
