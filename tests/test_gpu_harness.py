@@ -52,6 +52,11 @@ def test_basic_sort_example():
     assert proc.returncode == 0 and "Result: PASSED" in proc.stdout
     proc = _run([os.path.join(BIN, "basic_sort"), "77777", "--int64", "--argsort", "--pinned"])
     assert proc.returncode == 0 and "Result: PASSED" in proc.stdout, proc.stdout[-1000:] + proc.stderr[-1000:]
+    # the same five calls on the sharded engine: 8 rank threads on the one GPU, both exchanges
+    proc = _run([os.path.join(BIN, "basic_sort"), "1000003", "--ranks", "8", "--argsort"])
+    assert proc.returncode == 0 and "Result: PASSED" in proc.stdout and "8 ranks, path waves," in proc.stdout, proc.stdout[-1000:] + proc.stderr[-1000:]
+    proc = _run([os.path.join(BIN, "basic_sort"), "500000", "--int64", "--ranks", "4", "--peer-stores"])
+    assert proc.returncode == 0 and "Result: PASSED" in proc.stdout and "path waves-p2p" in proc.stdout, proc.stdout[-1000:] + proc.stderr[-1000:]
 
 
 def test_pinned_transfers_and_sweep_csv(tmp_path):
