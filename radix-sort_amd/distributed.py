@@ -19,7 +19,7 @@ radix-sort_amd/host/ShardPlanner.cpp through planner.py — the same code the C+
                strategy "waves-p2p": the receive buffers are peer-visible device memory; `rsx_msd_plan` computes every segment's
                place in its destination ON THE DEVICE from the gathered table (no host round trip in front of the data), and one
                `rsx_msd_push` per wave copies this rank's segments straight into the owners' buffers over xGMI on a second
-               stream, each wave closed by a one-word all_reduce (its fence)
+               stream, each GROUP of waves (below) closed by a one-word all_reduce (its fence)
       sort     the waves are sorted in DOUBLING GROUPS {0} {1} {2,3} {4..7} ...: wave 0 as soon as it has landed (the exposed part
                of the exchange is 1/k of it), the later groups — gap-free in the receive buffer — together, at the big-sort rate, while
                the next group is on the links.  A group of 2^j aligned buckets shares the top B - j bits, so its sort
@@ -572,13 +572,14 @@ class ShardedSorter:
         if self._push is None:
             self._push = torch.cuda.Stream(device=keys.device)
         fences = []
+        closes_group = {first + nwaves - 1 for first, nwaves in groups}
 
         def push(w):
             with torch.cuda.stream(self._push):
                 self.engine.msd_push(w, staging.data_ptr(), peer["keys_dev"].data_ptr(), staging_payload.data_ptr() if payload is not None else None,
                                      peer["pays_dev"].data_ptr() if payload is not None else None, self.push_parts, self._push.cuda_stream)
-                # every rank's push of wave w has finished: what this rank received of it is complete
-                fences.append(self.dist.all_reduce(peer["fence"], async_op=True))
+                # one fence per GROUP, behind its last wave: every rank's pushes of the group have finished, what this rank received of it is complete
+                fences.append(self.dist.all_reduce(peer["fence"], async_op=True) if w in closes_group else None)
 
         with torch.cuda.stream(self._push):
             work.wait()

@@ -544,12 +544,14 @@ int RadixSortMultiGPU<T>::pipelinedPeerStores(Rank& r)
     RSX_STEP(r.comm->allGather(r.d_row, r.d_table, sizeof(Row)), "all_gather of the count rows");
     RSX_STEP(rsx_msd_scatter(r.E, r.keys, r.pay, r.n, r.staging, r.spay), "rsx_msd_scatter");
     RSX_STEP(rsx_msd_plan(r.E, r.d_table, kRowLen, kCapsAt, r.rank, mGrouping, r.cstream), "rsx_msd_plan");
+    const auto groups = shardplan::wave_groups(k, mGrouping);
+    std::vector<bool> closesGroup(static_cast<std::size_t>(k), false);
+    for (const auto& g : groups) closesGroup[static_cast<std::size_t>(g.first + g.second - 1)] = true;
     auto push = [&](int w) {
         int rc = rsx_msd_push(r.E, w, r.staging, pay ? r.spay : nullptr, r.d_peerKeys, pay ? r.d_peerPays : nullptr, mOpt.pushParts, r.cstream);
-        if (rc == RSX_OK) rc = r.comm->fence();          // every rank's push of this wave has finished
+        if (rc == RSX_OK && closesGroup[static_cast<std::size_t>(w)]) rc = r.comm->fence();      // one fence per GROUP: every rank's pushes of the group have finished
         return rc;
     };
-    const auto groups = shardplan::wave_groups(k, mGrouping);
     int issued = 0;
     auto issueUpTo = [&](int end) {
         for (; issued < end; ++issued) {
