@@ -170,3 +170,61 @@ def test_8bit_scatter_as_a_staying_grid_is_exact(mod, oracle, dt, n, stay):
             for bad in (-2, 9):
                 with pytest.raises(mod.RadixSortError):
                     e.set_option(mod.XOPT_REORDER8_STAY, bad)
+
+
+@pytest.mark.parametrize("strategy", ["waves", "waves-p2p"])
+def test_engine_status_of_one_rank_stops_every_rank_of_the_sharded_sort(mod, oracle, strategy):
+    """The fused scan's time-out word of ONE rank's engine (raised through the experiments build's test hook) travels in the count row the
+    sharded sort gathers anyway — on the peer-store path it is folded into the device-side plan's verdict (bit 32 + rank), no host round trip —
+    and EVERY rank raises EngineStatusError in that step; nobody pushes, nobody hangs, and the next step sorts (the word is reported once)."""
+    import threading
+
+    import torch
+    from radix_sort_amd.distributed import EngineStatusError, ShardedSorter
+    from test_gpu_sharded import _Loopback
+    world, n = 4, 60000
+    full = oracle.dataset("SeededUniform", "uint32", n * world, seed=13)
+    hub = _Loopback(world)
+    outcomes, results, errors = [None] * world, [None] * world, []
+    p2p = strategy == "waves-p2p"
+
+    def run(rank):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                keys = torch.from_numpy(full[rank * n:(rank + 1) * n].copy().view(np.int32)).cuda()
+                staging = torch.empty_like(keys)
+                recv = None if p2p else torch.empty(2 * n, dtype=keys.dtype, device="cuda")
+                obuf = torch.empty(2 * n, dtype=keys.dtype, device="cuda")
+                with mod.Engine("uint32", 2 * n) as eng:
+                    eng.set_stream(stream.cuda_stream)
+                    sorter = ShardedSorter(eng, rank, world, 32, hub.view(rank), strategy=strategy)
+                    if p2p:
+                        sorter.setup_peer_exchange(2 * n, keys.device)
+                    try:
+                        if rank == 2:
+                            eng.set_option(mod.XOPT_DEBUG_RAISE_SCAN_TIMEOUT, 1)      # the store a starved scan workgroup makes, on the engine's stream
+                            torch.cuda.synchronize()
+                        try:
+                            sorter.sort(keys, staging, recv, None, None, None, obuf, None)
+                            outcomes[rank] = "sorted"
+                        except EngineStatusError as exc:
+                            outcomes[rank] = str(exc)
+                        n_local = sorter.sort(keys, staging, recv, None, None, None, obuf, None)      # reported once: the next step runs
+                        eng.sync()
+                        results[rank] = obuf[:n_local].cpu().numpy().view(np.uint32)
+                    finally:
+                        if p2p:
+                            sorter.close_peer_exchange()
+        except Exception as exc:   # noqa: BLE001
+            errors.append(exc)
+            hub.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert all(o is not None and o.startswith("rank(s) [2] reported an engine error") for o in outcomes), outcomes
+    assert np.array_equal(np.concatenate(results), np.sort(full))
