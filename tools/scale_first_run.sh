@@ -22,7 +22,10 @@ python - "$O" "$N" <<'PY'
 import glob, json, os, sys
 out, n = sys.argv[1], int(sys.argv[2])
 one = json.loads([l for l in open(os.path.join(out, "n1.json")) if l.startswith("{")][-1])
-print(f"single GPU: {one['value'] / 1e3:.1f} Gkeys/s ({one['ms_per_step']} ms per 2^28 keys)")
+if one.get("value") is None:
+    print("single GPU: rehearsal line (no value)")
+else:
+    print(f"single GPU: {one['value'] / 1e3:.1f} Gkeys/s ({one['ms_per_step']} ms per 2^28 keys)")
 for f in sorted(glob.glob(os.path.join(out, "*.json"))):
     if f.endswith("n1.json"):
         continue
@@ -31,5 +34,8 @@ for f in sorted(glob.glob(os.path.join(out, "*.json"))):
         print(f"{os.path.basename(f):28s} no line")
         continue
     d = json.loads(lines[-1])
+    if d.get("value") is None:          # a rehearsal line (RSX_BENCH_SHARED_GPU=1): checks the plumbing, carries no number
+        print(f"{os.path.basename(f):28s} rehearsal, verified: {d['config']['verified'][:60]}  {d['config']['parallelism'][:90]}")
+        continue
     print(f"{os.path.basename(f):28s} {d['ms_per_step']:8.3f} ms  {d['value'] / 1e3:7.1f} Gkeys/s  {d['value'] / (n * one['value']):.2f} of {n} x single  {d['config']['parallelism'][:90]}  {d.get('sharded_phases_ms')}")
 PY
