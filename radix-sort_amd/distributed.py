@@ -74,11 +74,6 @@ def default_partition_bits(world_size: int) -> int:
     return max(4, min(8, (world_size - 1).bit_length() + 3))
 
 
-def local_pass_units(key_bits: int, partition_bits: int) -> int:
-    """4-bit pass units the local sort of a wave needs: its keys share the top `partition_bits` bits."""
-    return (key_bits - partition_bits + 3) // 4
-
-
 def bucket_owner(world_size: int) -> list[int]:
     """Bucket b (0..15, ascending key order) -> owning rank; contiguous, monotone ranges."""
     if not 1 <= world_size <= RADIX:

@@ -163,9 +163,9 @@ def test_peer_access_decision():
 def test_process_identity_is_stable_and_fits_int64():
     import __graft_entry__ as entry
     entry.load_package()
-    from radix_sort_amd.distributed import default_partition_bits, local_pass_units, process_identity
+    from radix_sort_amd.distributed import default_partition_bits, group_pass_units, process_identity
     a, b = process_identity(0), process_identity(3)
     assert a[:3] == b[:3] and (a[3], b[3]) == (0, 3) and a[2] == os.getpid()
     assert all(0 <= v < (1 << 63) for v in a)
     assert [default_partition_bits(w) for w in (1, 2, 4, 8, 16)] == [4, 4, 5, 6, 7]
-    assert [local_pass_units(32, b) for b in (1, 4, 5, 6, 8)] == [8, 7, 7, 7, 6] and local_pass_units(64, 6) == 15
+    assert [group_pass_units(32, b, 1) for b in (1, 4, 5, 6, 8)] == [8, 7, 7, 7, 6] and group_pass_units(64, 6, 1) == 15
